@@ -1,0 +1,82 @@
+// api.hip — C ABI of libcjs_hip.so (include/cjs_hip.h): contexts, host-buffer entry points,
+// stage-level entry points.  No CPU fallback: without a HIP device every call fails loudly.
+#include "cjs_internal.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace cjs;
+
+extern "C" {
+
+const char* cjs_version(void) { return "cjs_hip 0.1 (gfx950)"; }
+
+int cjs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void cjs_free(void* p) { free(p); }
+
+const char* cjs_strerror(int code) {
+  switch (code) {
+    case CJS_OK: return "ok";
+    case CJS_E_NOT_BZIP_DATA: return "Not bzip data";
+    case CJS_E_DATA_ERROR: return "Data error";
+    case CJS_E_OUT_OF_MEMORY: return "Out of memory";
+    case CJS_E_OBSOLETE_INPUT: return "Obsolete (pre 0.9.5) bzip format not supported.";
+    case CJS_E_BAD_LEVEL: return "Invalid block size multiplier";
+    case CJS_E_BAD_MAGIC: return "Bad magic";
+    case CJS_E_NO_DEVICE: return "no HIP device available (this library has no CPU fallback)";
+    case CJS_E_HIP: return "HIP runtime error";
+    case CJS_E_INVALID_ARG: return "invalid argument";
+    case CJS_E_OUTPUT_TOO_SMALL: return "output buffer too small";
+    case CJS_E_UNSUPPORTED: return "not supported";
+    default: return "unknown error";
+  }
+}
+
+}  // extern "C"
+
+namespace cjs {
+
+int select_device(const cjs_opts* opts) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CJS_E_NO_DEVICE;
+  if (opts && opts->struct_size >= sizeof(cjs_opts) && opts->device >= 0) {
+    if (opts->device >= n) return CJS_E_INVALID_ARG;
+    CJS_HIP_TRY(hipSetDevice(opts->device));
+  }
+  return 0;
+}
+
+}  // namespace cjs
+
+extern "C" int cjs_stage_bwt(const uint8_t* in, size_t n, int block_len, int cyclic, uint8_t* out, int32_t* pidx, const cjs_opts* opts) {
+  CJS_TRY(select_device(opts));
+  if (n == 0) return 0;
+  if (block_len <= 0) return CJS_E_INVALID_ARG;
+  const uint32_t stride = (uint32_t)block_len;
+  const uint32_t nb = (uint32_t)((n + stride - 1) / stride);
+  const uint32_t n_last = (uint32_t)(n - (size_t)(nb - 1) * stride);
+  Arena arena;
+  CJS_TRY(arena.init(BwtWork::bytes_needed(n) + 2 * ((n + 511) & ~(size_t)255) + 4 * (size_t)nb + 8192));
+  BwtWork w;
+  int rc = w.carve(arena, n);
+  uint8_t* d_T = arena.take<uint8_t>(n);
+  uint8_t* d_U = arena.take<uint8_t>(n);
+  uint32_t* d_p = arena.take<uint32_t>(nb);
+  hipStream_t s = nullptr;
+  if (!rc && (!d_T || !d_U || !d_p)) rc = CJS_E_OUT_OF_MEMORY;
+  if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpyAsync(d_T, in, n, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) rc = bwt_run(s, w, d_T, nb, stride, n_last, cyclic != 0, d_U, d_p, opts && opts->struct_size >= sizeof(cjs_opts) ? opts->stats : nullptr);
+  if (!rc && hipMemcpyAsync(out, d_U, n, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpyAsync(pidx, d_p, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+  if (s) (void)hipStreamDestroy(s);
+  if (w.h_counters) (void)hipHostFree(w.h_counters);
+  arena.destroy();
+  return rc;
+}

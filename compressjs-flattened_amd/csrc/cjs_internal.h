@@ -1,0 +1,75 @@
+// cjs_internal.h — shared host-side declarations of the HIP library (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include "cjs_hip.h"
+
+#define CJS_HIP_TRY(expr)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      fprintf(stderr, "[cjs_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return _e == hipErrorOutOfMemory ? CJS_E_OUT_OF_MEMORY : CJS_E_HIP;                    \
+    }                                                                                       \
+  } while (0)
+#define CJS_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+namespace cjs {
+
+// simple device arena: one hipMalloc, bump allocation, 256-byte aligned
+struct Arena {
+  uint8_t* base = nullptr;
+  size_t cap = 0, used = 0;
+  int init(size_t bytes) {
+    CJS_HIP_TRY(hipMalloc((void**)&base, bytes));
+    cap = bytes; used = 0;
+    return 0;
+  }
+  void destroy() { if (base) (void)hipFree(base); base = nullptr; cap = used = 0; }
+  template <typename T> T* take(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    if (used + bytes > cap) return nullptr;
+    T* p = (T*)(base + used);
+    used += bytes;
+    return p;
+  }
+};
+
+struct EventTimer {   // accumulates device time of bracketed regions on one stream
+  hipStream_t s;
+  hipEvent_t a, b;
+  bool ok = false;
+  int init(hipStream_t st) { s = st; CJS_HIP_TRY(hipEventCreate(&a)); CJS_HIP_TRY(hipEventCreate(&b)); ok = true; return 0; }
+  void destroy() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); ok = false; } }
+  void start() { (void)hipEventRecord(a, s); }
+  double stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+};
+
+constexpr uint32_t RS_TILE = 4096;   // radix-sort tile (256 threads x 16 keys)
+
+// Workspace of the suffix sorter for up to `cap` suffixes (all blocks of a batch together).
+struct BwtWork {
+  size_t cap = 0;
+  uint64_t* key[2] = {nullptr, nullptr};
+  uint32_t* val[2] = {nullptr, nullptr};
+  uint32_t* pos[2] = {nullptr, nullptr};
+  uint32_t* gord = nullptr;
+  uint32_t* R = nullptr;
+  uint32_t* SA = nullptr;
+  uint32_t* hist = nullptr;      // 256 * tiles
+  uint32_t* bintot = nullptr;    // 256
+  uint32_t* tile_cnt = nullptr;  // 3 * tiles (+ scanned copies)
+  uint32_t* counters = nullptr;  // 16
+  uint32_t* h_counters = nullptr;  // pinned host mirror
+  static size_t bytes_needed(size_t cap);
+  int carve(Arena& a, size_t cap);
+};
+
+// Suffix-sorts nb blocks (block k = d_T[k*stride .. +n_k), n_k = stride except the last = n_last)
+// and writes the BWT bytes to d_U (same layout) and the primary indices to d_pidx[nb].
+int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t stride, uint32_t n_last,
+            bool cyclic, uint8_t* d_U, uint32_t* d_pidx, cjs_stats* stats);
+
+}  // namespace cjs

@@ -1,0 +1,113 @@
+/* cjs_hip.h — C ABI of the MI355X-native block-sorting core (libcjs_hip.so).
+ *
+ * This is the drop-in boundary for the compressjs Bzip2 / BWTC hot path: exactly what an FFI
+ * binding of the reference's per-algorithm `compressFile` / `decompressFile` would call
+ * (N-API shim: compressjs-flattened_amd/js/cjs_napi.cc; ctypes: tests/support.py).
+ * Plain pointers and sizes only.  Functions never throw; they return 0 or a negative code.
+ * Every entry point needs a HIP device: without one the call fails with CJS_E_NO_DEVICE
+ * (there is NO CPU fallback in this library).
+ *
+ * J/ = /root/reference/ (reference source, cited for parity checks).
+ */
+#ifndef CJS_HIP_H
+#define CJS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes.  -1..-8 keep the reference's Err table (J/Bzip2_joined_.js:1365-1375) */
+#define CJS_OK 0
+#define CJS_E_NOT_BZIP_DATA (-2)   /* TypeError "Not bzip data[: bad magic|level out of range]" */
+#define CJS_E_DATA_ERROR (-5)      /* TypeError "Data error[: Bad block CRC ...]" */
+#define CJS_E_OUT_OF_MEMORY (-6)
+#define CJS_E_OBSOLETE_INPUT (-7)  /* randomised blocks */
+#define CJS_E_BAD_LEVEL (-20)      /* Error('Invalid block size multiplier') J/Bzip2_joined_.js:2208 */
+#define CJS_E_BAD_MAGIC (-21)      /* Error("Bad magic") J/BWTC_joined_.js:559-565 */
+#define CJS_E_NO_DEVICE (-30)      /* no HIP device / HIP runtime error */
+#define CJS_E_HIP (-31)
+#define CJS_E_INVALID_ARG (-32)
+#define CJS_E_OUTPUT_TOO_SMALL (-33)
+#define CJS_E_UNSUPPORTED (-34)
+
+/* ---- options (all optional; pass NULL for defaults) */
+typedef struct cjs_stats {
+  double ms_total;        /* device time of the whole call (hipEvents on the work stream) */
+  double ms_rle1;         /* RLE1 + CRC + block boundaries */
+  double ms_bwt;          /* suffix sort + BWT emit */
+  double ms_mtf;          /* MTF + RLE2 + histogram */
+  double ms_huff;         /* Huffman table construction / optimisation */
+  double ms_pack;         /* bit packing + stream assembly */
+  double ms_bwt_dominant; /* average launch duration of the dominant kernel (radix scatter) */
+  uint64_t bwt_dominant_launches;
+  uint64_t bwt_dominant_bytes;   /* algorithmic bytes moved by those launches */
+  uint64_t blocks;
+  uint64_t bytes_in, bytes_out;
+  uint32_t bwt_rounds;
+} cjs_stats;
+
+typedef struct cjs_opts {
+  uint32_t struct_size;   /* sizeof(cjs_opts) */
+  int32_t device;         /* HIP device ordinal; -1 = current device */
+  uint32_t n_devices;     /* host-buffer entry points: shard blocks over this many GPUs (0/1 = one) */
+  uint32_t flags;
+  cjs_stats *stats;       /* optional out */
+} cjs_opts;
+
+/* ---- host-buffer entry points (what the JS fronts bind).
+ * cjs_bzip2_compress   replaces Bzip2.compressFile    J/Bzip2_joined_.js:2199-2249
+ * cjs_bzip2_decompress replaces Bzip2.decompressFile  J/Bzip2_joined_.js:1769-1796
+ * cjs_bwtc_compress    replaces BWTC.compressFile     J/BWTC_joined_.js:1698-1825
+ * cjs_bwtc_decompress  replaces BWTC.decompressFile   J/BWTC_joined_.js:1827-1920
+ * `*out` is malloc'd by the library; release with cjs_free.  level: 1..9 (bzip2: else
+ * CJS_E_BAD_LEVEL; bwtc: else 9, J/BWTC_joined_.js:1702-1705). */
+int cjs_bzip2_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n, const cjs_opts *opts);
+int cjs_bzip2_decompress(const uint8_t *in, size_t n, int multistream, uint8_t **out, size_t *out_n, const cjs_opts *opts);
+int cjs_bwtc_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n, const cjs_opts *opts);
+int cjs_bwtc_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, const cjs_opts *opts);
+void cjs_free(void *p);
+const char *cjs_strerror(int code);
+int cjs_device_count(void);
+const char *cjs_version(void);
+
+/* ---- device-resident pipeline (input already in HBM, output left in HBM): what bench.py times.
+ * A context owns the per-GPU workspace (sized for max_input bytes at `level`) and one stream. */
+typedef struct cjs_ctx cjs_ctx;
+int cjs_ctx_create(cjs_ctx **ctx, int device, size_t max_input, int level);
+void cjs_ctx_destroy(cjs_ctx *ctx);
+/* d_in/d_out are device pointers; d_out has out_cap bytes; *out_n receives the stream length.
+ * Synchronous on return (the context stream has drained). */
+int cjs_bzip2_compress_device(cjs_ctx *ctx, const uint8_t *d_in, size_t n, int level,
+                              uint8_t *d_out, size_t out_cap, size_t *out_n, cjs_stats *stats);
+/* Sharded variant for one-process-per-GPU jobs: compress only blocks [first, first+count) of the
+ * stream held (replicated) in d_in, writing the block bit-strings from bit 0 of d_out WITHOUT the
+ * 'BZh' header / trailer.  Returns the bit length and the per-block CRCs so the ranks can fold the
+ * stream CRC and bit offsets (host side, a few bytes per rank; no data-path collective).
+ * count = -1 means "to the end".  *total_blocks receives the number of blocks of the stream. */
+int cjs_bzip2_compress_device_range(cjs_ctx *ctx, const uint8_t *d_in, size_t n, int level,
+                                    long first_block, long count, uint8_t *d_out, size_t out_cap,
+                                    uint64_t *out_bits, uint32_t *block_crcs, long crc_cap,
+                                    long *total_blocks, cjs_stats *stats);
+
+/* ---- stage-level entry points (host buffers; used by the parity tests to localise a mismatch).
+ * in = nb consecutive blocks of block_len bytes (last one may be shorter).
+ * cjs_stage_bwt: cyclic!=0 -> BWT.bwtransform2 semantics (J/Bzip2_joined_.js:928-971, Q4),
+ *                cyclic==0 -> BWT.bwtransform semantics (J/BWTC_joined_.js:1125-1145). */
+int cjs_stage_bwt(const uint8_t *in, size_t n, int block_len, int cyclic, uint8_t *out, int32_t *pidx, const cjs_opts *opts);
+/* readBlock (J/Bzip2_joined_.js:1954-1985) for the whole stream: RLE1 bytes of all blocks,
+ * concatenated with stride = level*100000-19; per block length / crc / input start */
+int cjs_stage_rle1(const uint8_t *in, size_t n, int level, uint8_t *blocks, size_t blocks_cap,
+                   uint32_t *block_len, uint32_t *block_crc, uint64_t *block_start, long cap, long *nblocks, const cjs_opts *opts);
+/* MTF + RLE2 (J/Bzip2_joined_.js:2064-2139) for nb blocks: U and block bytes with the same layout as
+ * cjs_stage_bwt; A = u16 symbols with stride block_len+1 */
+int cjs_stage_mtf(const uint8_t *U, const uint8_t *blocks, size_t n, int block_len, uint16_t *A, uint32_t *npos,
+                  uint32_t *freq /* nb*258 */, uint32_t *alphabet /* nb */, const cjs_opts *opts);
+/* Huffman tables + selectors (J/Bzip2_joined_.js:1989-2054,2147-2163) for one symbol stream */
+int cjs_stage_huff(const uint16_t *A, uint32_t npos, uint32_t alphabet, uint8_t *selectors, uint8_t *lengths /* 6*258 */,
+                   uint32_t *ngroups, const cjs_opts *opts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

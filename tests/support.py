@@ -176,14 +176,32 @@ class HipLib(_StreamLib):
             raise RuntimeError("libcjs_hip.so missing: run `make hip` (python __graft_entry__.py)")
         L = self.L = ctypes.CDLL(path)
         S, I, V = ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p
-        for name in ("cjs_bzip2_compress", "cjs_bwtc_compress"):
-            getattr(L, name).argtypes = [u8p, S, I, ctypes.POINTER(u8p), ctypes.POINTER(S), V]
-        L.cjs_bzip2_decompress.argtypes = [u8p, S, I, ctypes.POINTER(u8p), ctypes.POINTER(S), V]
-        L.cjs_bwtc_decompress.argtypes = [u8p, S, ctypes.POINTER(u8p), ctypes.POINTER(S), V]
-        L.cjs_free.argtypes = [V]
+        PS = ctypes.POINTER(S)
+        PP = ctypes.POINTER(u8p)
+        sigs = {
+            "cjs_bzip2_compress": [u8p, S, I, PP, PS, V],
+            "cjs_bwtc_compress": [u8p, S, I, PP, PS, V],
+            "cjs_bzip2_decompress": [u8p, S, I, PP, PS, V],
+            "cjs_bwtc_decompress": [u8p, S, PP, PS, V],
+            "cjs_free": [V],
+            "cjs_strerror": [I],
+            "cjs_device_count": [],
+            "cjs_stage_bwt": [V, S, I, I, V, V, V],
+            "cjs_stage_rle1": [V, S, I, V, S, V, V, V, ctypes.c_long, ctypes.POINTER(ctypes.c_long), V],
+            "cjs_stage_mtf": [V, V, S, I, V, V, V, V, V],
+            "cjs_stage_huff": [V, ctypes.c_uint32, ctypes.c_uint32, V, V, V, V],
+        }
+        self.missing = []
+        for name, args in sigs.items():
+            fn = getattr(L, name, None)
+            if fn is None:      # symbol missing from the C ABI (tests/test_abi.py fails on this)
+                self.missing.append(name)
+                continue
+            fn.argtypes = args
+            fn.restype = I
         L.cjs_strerror.restype = ctypes.c_char_p
-        L.cjs_strerror.argtypes = [I]
-        L.cjs_device_count.restype = I
+        L.cjs_version.restype = ctypes.c_char_p
+        L.cjs_free.restype = None
 
     def _free(self, p):
         self.L.cjs_free(p)
@@ -199,3 +217,49 @@ class HipLib(_StreamLib):
 
     def bwtc_decompress(self, data):
         return self._call_stream(self.L.cjs_bwtc_decompress, self._free, data, tail=(None,))
+
+    def stage_bwt(self, data, block_len, cyclic):
+        data = as_u8(data)
+        nb = max(1, -(-data.size // block_len))
+        U = np.zeros(max(data.size, 1), dtype=np.uint8)
+        pidx = np.zeros(nb, dtype=np.int32)
+        rc = self.L.cjs_stage_bwt(data.ctypes.data, data.size, block_len, 1 if cyclic else 0, U.ctypes.data, pidx.ctypes.data, None)
+        return rc, U[: data.size], pidx
+
+    def stage_rle1(self, data, level):
+        data = as_u8(data)
+        cap = level * 100000 - 19
+        maxb = data.size // (cap * 4 // 5) + 2
+        blocks = np.zeros(maxb * cap, dtype=np.uint8)
+        blen = np.zeros(maxb, dtype=np.uint32)
+        bcrc = np.zeros(maxb, dtype=np.uint32)
+        bstart = np.zeros(maxb + 1, dtype=np.uint64)
+        nb = ctypes.c_long(0)
+        keep = data if data.size else np.zeros(1, np.uint8)
+        rc = self.L.cjs_stage_rle1(keep.ctypes.data, data.size, level, blocks.ctypes.data, blocks.size, blen.ctypes.data,
+                                   bcrc.ctypes.data, bstart.ctypes.data, maxb, ctypes.byref(nb), None)
+        if rc:
+            return rc, None
+        n = nb.value
+        return 0, [(blocks[k * cap: k * cap + int(blen[k])].copy(), int(bcrc[k]), int(bstart[k])) for k in range(n)]
+
+    def stage_mtf(self, U, blocks, block_len):
+        U = as_u8(U)
+        blocks = as_u8(blocks)
+        nb = max(1, -(-U.size // block_len))
+        A = np.zeros(nb * (block_len + 1), dtype=np.uint16)
+        npos = np.zeros(nb, dtype=np.uint32)
+        freq = np.zeros(nb * 258, dtype=np.uint32)
+        asz = np.zeros(nb, dtype=np.uint32)
+        rc = self.L.cjs_stage_mtf(U.ctypes.data, blocks.ctypes.data, U.size, block_len, A.ctypes.data, npos.ctypes.data,
+                                  freq.ctypes.data, asz.ctypes.data, None)
+        return rc, A.reshape(nb, block_len + 1), npos, freq.reshape(nb, 258), asz
+
+    def stage_huff(self, A, alphabet):
+        A = np.ascontiguousarray(A, dtype=np.uint16)
+        nsel = (A.size + 49) // 50
+        sel = np.zeros(max(nsel, 1), dtype=np.uint8)
+        lens = np.zeros(6 * 258, dtype=np.uint8)
+        ng = ctypes.c_uint32(0)
+        rc = self.L.cjs_stage_huff(A.ctypes.data, A.size, alphabet, sel.ctypes.data, lens.ctypes.data, ctypes.byref(ng), None)
+        return rc, ng.value, sel[:nsel], lens.reshape(6, 258)[: ng.value, : alphabet + 2]
