@@ -1,6 +1,7 @@
 // api.hip — C ABI of libcjs_hip.so (include/cjs_hip.h): contexts, host-buffer entry points,
 // stage-level entry points.  No CPU fallback: without a HIP device every call fails loudly.
 #include "cjs_internal.h"
+#include "rle1.h"
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -77,6 +78,42 @@ extern "C" int cjs_stage_bwt(const uint8_t* in, size_t n, int block_len, int cyc
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
   if (s) (void)hipStreamDestroy(s);
   if (w.h_counters) (void)hipHostFree(w.h_counters);
+  arena.destroy();
+  return rc;
+}
+
+extern "C" int cjs_stage_rle1(const uint8_t* in, size_t n, int level, uint8_t* blocks, size_t blocks_cap,
+                              uint32_t* block_len, uint32_t* block_crc, uint64_t* block_start, long cap_blocks, long* nblocks,
+                              const cjs_opts* opts) {
+  CJS_TRY(select_device(opts));
+  if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;
+  const uint32_t cap = (uint32_t)level * 100000u - 19u;
+  *nblocks = 0;
+  if (n == 0) return 0;
+  Arena arena;
+  const size_t maxb = Rle1Work::max_blocks_for(n, cap);
+  CJS_TRY(arena.init(Rle1Work::bytes_needed(n, cap) + n + maxb * cap + 65536));
+  Rle1Work w;
+  int rc = w.carve(arena, n, cap);
+  uint8_t* d_in = arena.take<uint8_t>(n);
+  uint8_t* d_blocks = arena.take<uint8_t>(maxb * cap);
+  hipStream_t s = nullptr;
+  if (!rc && (!d_in || !d_blocks)) rc = CJS_E_OUT_OF_MEMORY;
+  if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  uint32_t nb = 0;
+  if (!rc) rc = rle1_run(s, w, d_in, n, d_blocks, &nb);
+  if (!rc && ((long)nb > cap_blocks || (size_t)nb * cap > blocks_cap)) rc = CJS_E_OUTPUT_TOO_SMALL;
+  if (!rc && nb) {
+    std::vector<RleBlock> hb(nb);
+    if (hipMemcpy(hb.data(), w.blocks, sizeof(RleBlock) * nb, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemcpy(block_len, w.block_len, 4 * (size_t)nb, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemcpy(block_crc, w.block_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemcpy(blocks, d_blocks, (size_t)nb * cap, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc) for (uint32_t k = 0; k < nb; k++) block_start[k] = hb[k].s;
+  }
+  *nblocks = (long)nb;
+  if (s) (void)hipStreamDestroy(s);
   arena.destroy();
   return rc;
 }

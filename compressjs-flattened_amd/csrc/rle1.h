@@ -1,0 +1,29 @@
+// rle1.h — stage 0 (RLE1 + block boundaries + CRC) workspace and entry point.
+#pragma once
+#include "cjs_internal.h"
+
+namespace cjs {
+
+struct RleBlock {
+  uint64_t s, e;       // input range consumed by the block
+  uint64_t r_end;      // end of the run that contains s (block-fresh chunking applies to [s, r_end))
+  uint64_t Gr;         // global emitted-byte prefix at r_end
+  uint32_t len;        // RLE1 output length (== cap for every block but possibly the last)
+  uint32_t base;       // bytes emitted by the first (re-chunked) run
+};
+
+struct Rle1Work {
+  size_t max_in = 0;
+  uint32_t cap = 0, max_blocks = 0, max_segs = 0;
+  uint64_t *fb = nullptr, *lb = nullptr, *gt = nullptr;
+  RleBlock* blocks = nullptr;
+  uint32_t *block_len = nullptr, *block_crc = nullptr, *nblocks = nullptr, *seg_crc = nullptr;
+  static size_t max_blocks_for(size_t max_in, uint32_t cap) { return max_in / ((size_t)cap * 4 / 5) + 2; }
+  static size_t max_segs_for(uint32_t cap) { return ((size_t)cap * 51 + 16383) / 16384 + 1; }
+  static size_t bytes_needed(size_t max_in, uint32_t cap);
+  int carve(Arena& a, size_t max_in, uint32_t cap);
+};
+
+int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint8_t* d_blocks, uint32_t* nblocks_host);
+
+}  // namespace cjs

@@ -1,0 +1,481 @@
+// rle1.hip — bzip2 stage 0 on the GPU: RLE1, block boundaries and per-block CRC-32.
+//
+// Replaces readBlock (J/Bzip2_joined_.js:1954-1985) + CRC32.updateCRC (:1048-1079) + the block
+// loop's use of them (:2233-2242).  The reference walks the input byte-serially; block k+1 starts
+// where block k's RLE1 OUTPUT reached level*100000-19 bytes and the run-chunking state is reset at
+// every block start.  Parallel formulation used here:
+//   c[i]  = bytes emitted when input byte i is consumed, under the "global" chunking (chunks of
+//           <= 255 equal bytes counted from the start of each maximal run):
+//           offset-in-chunk d' = (i - runstart) % 255 : d'<3 -> 1 (literal), d'==3 -> 2 (literal +
+//           count byte), d'>=4 -> 0 (absorbed into the count byte)
+//   G     = exclusive prefix sum of c (per 4096-byte tile: G_tile, then in-tile scan)
+//   a block that starts at s re-chunks only the run that contains s (closed form); after that
+//   run the global chunking applies again, so its end is found by a search on G.
+// Kernels: tile summaries -> tile scans -> serial-over-blocks walk by ONE workgroup (k-ary search
+// over G_tile + in-tile scan; O(#blocks) steps) -> materialise RLE1 bytes -> CRC (slice + GF(2)
+// combine).  Integer/byte work, HBM-bound streaming reads.
+#include "cjs_internal.h"
+#include "prims.hpp"
+#include "rle1.h"
+
+namespace cjs {
+
+constexpr uint32_t RT = 4096;          // input bytes per tile
+constexpr uint64_t NONE64 = ~0ull;
+
+__device__ __forceinline__ uint32_t emitted_fresh(uint64_t m) {   // output bytes after consuming m bytes of one run (fresh chunking)
+  const uint64_t q = m / 255; const uint32_t r = (uint32_t)(m % 255);
+  return (uint32_t)(5 * q) + (r < 4 ? r : 5u);
+}
+
+// Per-thread view of ITEMS consecutive positions starting at p0: boundary flags and the run start
+// governing the first position.  BLOCK threads cover BLOCK*ITEMS positions from tile_start.
+// carry = start of the run that contains tile_start when tile_start itself is not a boundary.
+template <int BLOCK, int ITEMS>
+__device__ __forceinline__ void run_starts(const uint8_t* __restrict__ in, uint64_t N, uint64_t tile_start, uint64_t carry,
+                                           uint32_t* smem /* BLOCK + 16 u32 */, uint8_t (&b)[ITEMS], uint32_t& bmask, uint64_t& rs_first) {
+  const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * ITEMS;
+  uint8_t prev = 0;
+  if (p0 > 0 && p0 - 1 < N) prev = in[p0 - 1];
+  bmask = 0;
+  uint32_t last = 0;     // (tile-relative index of my last boundary)+1
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    const uint64_t p = p0 + j;
+    b[j] = p < N ? in[p] : 0;
+    const bool bd = p < N && (p == 0 || b[j] != prev);
+    if (bd) { bmask |= 1u << j; last = (uint32_t)(p - tile_start) + 1u; }
+    prev = b[j];
+  }
+  const uint32_t im = block_incl_max<BLOCK>(last, smem);
+  smem[16 + threadIdx.x] = im;
+  __syncthreads();
+  const uint32_t ex = threadIdx.x ? smem[16 + threadIdx.x - 1] : 0u;
+  __syncthreads();
+  rs_first = ex ? tile_start + ex - 1 : carry;
+}
+
+// ---- P1: per tile first / last boundary (global position + 1; 0 = none)
+__global__ __launch_bounds__(256) void rle_tile_summary(const uint8_t* __restrict__ in, uint64_t N, uint64_t* __restrict__ fb, uint64_t* __restrict__ lb) {
+  __shared__ uint32_t smin[4], smax[4];
+  const uint64_t tile_start = (uint64_t)blockIdx.x * RT, p0 = tile_start + (uint64_t)threadIdx.x * 16;
+  uint8_t prev = 0;
+  if (p0 > 0 && p0 - 1 < N) prev = in[p0 - 1];
+  uint32_t first = 0xFFFFFFFFu, last = 0;
+  for (int j = 0; j < 16; j++) {
+    const uint64_t p = p0 + j;
+    if (p < N) {
+      const uint8_t c = in[p];
+      if (p == 0 || c != prev) { const uint32_t rel = (uint32_t)(p - tile_start); if (first == 0xFFFFFFFFu) first = rel; last = rel + 1; }
+      prev = c;
+    }
+  }
+  first = wave_min(first); last = wave_max(last);
+  if (lane_id() == 0) { smin[wave_id()] = first; smax[wave_id()] = last; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t f = smin[0], l = smax[0];
+    for (int i = 1; i < 4; i++) { f = smin[i] < f ? smin[i] : f; l = smax[i] > l ? smax[i] : l; }
+    fb[blockIdx.x] = f == 0xFFFFFFFFu ? 0 : tile_start + f + 1;
+    lb[blockIdx.x] = l ? tile_start + l : 0;     // (tile_start + l-1) + 1
+  }
+}
+
+// ---- P2: run_start_in[t] = start of the run containing the tile's first byte (from earlier tiles);
+//          next_bnd[t] = first boundary in later tiles (N if none).  One workgroup.
+__global__ __launch_bounds__(1024) void rle_scan_boundaries(uint64_t* __restrict__ fb, uint64_t* __restrict__ lb, uint32_t Tn, uint64_t N) {
+  __shared__ unsigned long long sm[16];
+  __shared__ unsigned long long arr[1024];
+  unsigned long long carry = 0;
+  for (uint32_t base = 0; base < Tn; base += 1024) {          // exclusive prefix max of lb (pos+1)
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long v = i < Tn ? lb[i] : 0ull;
+    const unsigned long long im = block_incl_max<1024>(v, sm);
+    arr[threadIdx.x] = im;
+    __syncthreads();
+    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
+    const unsigned long long cmx = arr[1023];
+    __syncthreads();
+    if (i < Tn) { const unsigned long long e = prev > carry ? prev : carry; lb[i] = e ? e - 1 : 0ull; }   // run start position
+    carry = cmx > carry ? cmx : carry;
+  }
+  // exclusive suffix min of fb (pos+1, 0 = none) -> position or N
+  unsigned long long scarry = 0;   // stored as (MAX - (pos+1)) + 1 style: use max-scan on inverted values, 0 = none
+  const uint32_t chunks = (Tn + 1023) / 1024;
+  for (uint32_t cidx = 0; cidx < chunks; cidx++) {
+    const uint32_t base = (chunks - 1 - cidx) * 1024;
+    const uint32_t i = base + (1023 - threadIdx.x);            // reversed order inside the chunk
+    const unsigned long long f = i < Tn ? fb[i] : 0ull;
+    const unsigned long long v = f ? (NONE64 - f) : 0ull;      // larger = smaller position
+    const unsigned long long im = block_incl_max<1024>(v, sm);
+    arr[threadIdx.x] = im;
+    __syncthreads();
+    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
+    const unsigned long long cmx = arr[1023];
+    __syncthreads();
+    if (i < Tn) {
+      const unsigned long long e = prev > scarry ? prev : scarry;
+      fb[i] = e ? (NONE64 - e) - 1 : N;                        // position of the next boundary after this tile
+    }
+    scarry = cmx > scarry ? cmx : scarry;
+  }
+}
+
+// ---- P3: per-tile emitted byte count under the global chunking
+__global__ __launch_bounds__(256) void rle_tile_count(const uint8_t* __restrict__ in, uint64_t N, const uint64_t* __restrict__ run_start_in,
+                                                      uint64_t* __restrict__ gt) {
+  __shared__ uint32_t smem[256 + 16];
+  const uint64_t tile_start = (uint64_t)blockIdx.x * RT;
+  uint8_t b[16]; uint32_t bm; uint64_t rs;
+  run_starts<256, 16>(in, N, tile_start, run_start_in[blockIdx.x], smem, b, bm, rs);
+  const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * 16;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint64_t p = p0 + j;
+    if (p < N) {
+      if ((bm >> j) & 1u) rs = p;
+      const uint32_t dp = (uint32_t)((p - rs) % 255);
+      cnt += dp < 3 ? 1u : dp == 3 ? 2u : 0u;
+    }
+  }
+  cnt = block_sum<256>(cnt, smem);
+  if (threadIdx.x == 0) gt[blockIdx.x] = cnt;
+}
+
+// ---- P4: exclusive prefix sum (u64) over tiles, one workgroup; gt[Tn] = total
+__global__ __launch_bounds__(1024) void rle_scan_counts(uint64_t* __restrict__ gt, uint32_t Tn) {
+  __shared__ unsigned long long sm[16];
+  unsigned long long carry = 0;
+  for (uint32_t base = 0; base < Tn; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    unsigned long long v = i < Tn ? gt[i] : 0ull, tot;
+    const unsigned long long ex = block_excl_sum<1024>(v, sm, tot);
+    if (i < Tn) gt[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) gt[Tn] = carry;
+}
+
+// in-tile helper for the walk (1024 threads x 4 positions): inclusive prefix of c at each position.
+// Returns via `firstpos` the smallest position p in the tile with gbase + incl(p) >= target (NONE64 if none),
+// and via `upto_sum` the sum of c over positions < upto.
+__device__ void walk_tile_eval(const uint8_t* __restrict__ in, uint64_t N, uint64_t tile_start, uint64_t carry, uint64_t gbase,
+                               uint64_t target, uint64_t upto, uint32_t* smem, unsigned long long* sh64,
+                               uint64_t& firstpos, uint32_t& upto_sum) {
+  uint8_t b[4]; uint32_t bm; uint64_t rs;
+  run_starts<1024, 4>(in, N, tile_start, carry, smem, b, bm, rs);
+  const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * 4;
+  uint32_t c[4], cnt = 0, below = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint64_t p = p0 + j;
+    c[j] = 0;
+    if (p < N) {
+      if ((bm >> j) & 1u) rs = p;
+      const uint32_t dp = (uint32_t)((p - rs) % 255);
+      c[j] = dp < 3 ? 1u : dp == 3 ? 2u : 0u;
+      cnt += c[j];
+      if (p < upto) below += c[j];
+    }
+  }
+  uint32_t tot;
+  uint32_t ex = block_excl_sum<1024>(cnt, smem, tot);
+  upto_sum = block_sum<1024>(below, smem);
+  if (threadIdx.x == 0) sh64[0] = NONE64;
+  __syncthreads();
+  unsigned long long mine = NONE64;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint64_t p = p0 + j;
+    ex += c[j];
+    if (p < N && mine == NONE64 && c[j] && gbase + ex >= target) mine = p;
+  }
+  if (mine != NONE64) atomicMin(&sh64[0], mine);
+  __syncthreads();
+  firstpos = sh64[0];
+  __syncthreads();
+}
+
+// ---- W: block boundaries.  ONE workgroup, serial over blocks.
+__global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in, uint64_t N, uint32_t cap, uint32_t Tn,
+                                                 const uint64_t* __restrict__ run_start_in, const uint64_t* __restrict__ next_bnd,
+                                                 const uint64_t* __restrict__ gt, RleBlock* __restrict__ blocks, uint32_t max_blocks,
+                                                 uint32_t* __restrict__ nblocks_out) {
+  __shared__ uint32_t smem[1024 + 16];
+  __shared__ unsigned long long sh64[2];
+  uint64_t s = 0;
+  uint32_t k = 0;
+  while (s < N && k < max_blocks) {
+    // end of the run containing s
+    const uint32_t ts = (uint32_t)(s / RT);
+    const uint64_t tile_end = ((uint64_t)(ts + 1) * RT < N) ? (uint64_t)(ts + 1) * RT : N;
+    if (threadIdx.x == 0) sh64[0] = NONE64;
+    __syncthreads();
+    {
+      unsigned long long mine = NONE64;
+      for (int j = 0; j < 4; j++) {
+        const uint64_t p = (uint64_t)ts * RT + (uint64_t)threadIdx.x * 4 + j;
+        if (p > s && p < tile_end && mine == NONE64 && in[p] != in[p - 1]) mine = p;
+      }
+      if (mine != NONE64) atomicMin(&sh64[0], mine);
+    }
+    __syncthreads();
+    uint64_t r_end = sh64[0];
+    __syncthreads();
+    if (r_end == NONE64) r_end = next_bnd[ts];
+    const uint64_t Lp = r_end - s;
+    const uint64_t q = Lp / 255; const uint32_t rr = (uint32_t)(Lp % 255);
+    const uint64_t g64 = 5 * q + (rr < 4 ? rr : 5u);
+    uint64_t e; uint32_t len, base = 0; uint64_t Gr = 0;
+    if (g64 >= cap) {                       // the block fills up inside this run
+      const uint32_t qq = cap / 5, rem = cap % 5;
+      const uint64_t m = rem == 0 ? (uint64_t)255 * (qq - 1) + 4 : (uint64_t)255 * qq + rem;
+      e = s + m; len = cap; base = cap;
+    } else {
+      base = (uint32_t)g64;
+      if (r_end >= N) { e = N; len = base; }
+      else {
+        const uint32_t tr = (uint32_t)(r_end / RT);
+        uint64_t fp; uint32_t below;
+        walk_tile_eval(in, N, (uint64_t)tr * RT, run_start_in[tr], 0, NONE64, r_end, smem, sh64, fp, below);
+        Gr = gt[tr] + below;
+        const uint64_t target = (uint64_t)cap - base + Gr;
+        // last tile t* in [tr, Tn) with gt[t*] < target  (gt[tr] <= Gr < target)
+        uint32_t lo = tr, hi = Tn;
+        while (hi - lo > 1) {
+          const uint32_t span = hi - lo, step = (span + 1023) / 1024;
+          if (threadIdx.x == 0) sh64[1] = lo;
+          __syncthreads();
+          const uint64_t idx = (uint64_t)lo + (uint64_t)threadIdx.x * step;
+          if (idx < hi && gt[idx] < target) atomicMax(&sh64[1], (unsigned long long)idx);
+          __syncthreads();
+          const uint32_t nlo = (uint32_t)sh64[1];
+          __syncthreads();
+          hi = (uint64_t)nlo + step < hi ? nlo + step : hi;
+          lo = nlo;
+        }
+        walk_tile_eval(in, N, (uint64_t)lo * RT, run_start_in[lo], gt[lo], target, 0, smem, sh64, fp, below);
+        if (fp != NONE64) { e = fp + 1; len = cap; }
+        else { e = N; len = (uint32_t)(base + (gt[Tn] - Gr)); }
+      }
+    }
+    if (threadIdx.x == 0) {
+      RleBlock bd; bd.s = s; bd.e = e; bd.r_end = r_end; bd.Gr = Gr; bd.len = len; bd.base = base;
+      blocks[k] = bd;
+    }
+    k++;
+    s = e;
+    if (len < cap) break;
+  }
+  if (threadIdx.x == 0) *nblocks_out = k;
+}
+
+// ---- R: materialise the RLE1 bytes of every block (grid = input tiles)
+__global__ __launch_bounds__(256) void rle_materialize(const uint8_t* __restrict__ in, uint64_t N, uint32_t cap,
+                                                       const uint64_t* __restrict__ run_start_in, const uint64_t* __restrict__ next_bnd,
+                                                       const uint64_t* __restrict__ gt, const RleBlock* __restrict__ blocks,
+                                                       const uint32_t* __restrict__ nblocks_p, uint8_t* __restrict__ out) {
+  __shared__ uint32_t smem[256 + 16];
+  __shared__ uint32_t nb_first[256];
+  const uint32_t nblocks = *nblocks_p;
+  const uint64_t tile_start = (uint64_t)blockIdx.x * RT;
+  if (nblocks == 0 || tile_start >= blocks[nblocks - 1].e) return;
+  uint8_t b[16]; uint32_t bm; uint64_t rs;
+  run_starts<256, 16>(in, N, tile_start, run_start_in[blockIdx.x], smem, b, bm, rs);
+  const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * 16;
+  // global c and its exclusive prefix inside the tile
+  uint32_t dpg[16], cnt = 0;
+  {
+    uint64_t r = rs;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t p = p0 + j;
+      dpg[j] = 255;
+      if (p < N) {
+        if ((bm >> j) & 1u) r = p;
+        dpg[j] = (uint32_t)((p - r) % 255);
+        cnt += dpg[j] < 3 ? 1u : dpg[j] == 3 ? 2u : 0u;
+      }
+    }
+  }
+  uint32_t tot;
+  const uint32_t exc = block_excl_sum<256>(cnt, smem, tot);
+  // next boundary after each position: tile-relative first boundary per thread, exclusive suffix-min over threads
+  const uint32_t myfirst = bm ? (uint32_t)threadIdx.x * 16u + (uint32_t)__builtin_ctz(bm) : 0xFFFFu;
+  {
+    const uint32_t q = 255 - threadIdx.x;                 // reversed thread order
+    nb_first[q] = myfirst == 0xFFFFu ? 0u : 0x10000u - myfirst;
+    __syncthreads();
+    const uint32_t v = nb_first[threadIdx.x];
+    const uint32_t im = block_incl_max<256>(v, smem);
+    __syncthreads();
+    nb_first[threadIdx.x] = im;
+    __syncthreads();
+  }
+  const uint32_t rq = 255 - threadIdx.x;
+  const uint32_t sfx = rq ? nb_first[rq - 1] : 0u;        // max over later threads of (0x10000 - first)
+  const uint64_t next_after_me = sfx ? tile_start + (0x10000u - sfx) : next_bnd[blockIdx.x];
+  // blocks overlapping this tile: first block with e > tile_start
+  uint32_t lo = 0, hi = nblocks - 1;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blocks[mid].e > tile_start) hi = mid; else lo = mid + 1; }
+  const uint64_t tile_end = tile_start + RT;
+  for (uint32_t k = lo; k < nblocks; k++) {
+    const RleBlock bd = blocks[k];
+    if (bd.s >= tile_end) break;
+    uint8_t* o = out + (size_t)k * cap;
+    uint32_t run = exc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t p = p0 + j;
+      const uint32_t cg = dpg[j] < 3 ? 1u : dpg[j] == 3 ? 2u : 0u;
+      if (p < N && p >= bd.s && p < bd.e) {
+        uint32_t dp; uint64_t off;
+        if (p < bd.r_end) { const uint64_t d = p - bd.s; dp = (uint32_t)(d % 255); off = 5 * (d / 255) + (dp < 4 ? dp : 4); }
+        else { dp = dpg[j]; off = (uint64_t)bd.base + (gt[blockIdx.x] + run - bd.Gr); }
+        if (dp < 4 && off < cap) {
+          o[off] = b[j];
+          if (dp == 3 && off + 1 < cap) {
+            // run end = next boundary after p
+            uint64_t re = next_after_me;
+            const uint32_t later = (j < 15) ? (bm >> (j + 1)) : 0u;
+            if (later) re = p + 1 + (uint32_t)__builtin_ctz(later);
+            uint64_t follow = re - (p + 1);
+            if (follow > 251) follow = 251;
+            if (off + 2 == cap) follow = 0;                    // count byte fills the block: stays 0 (Q2)
+            o[off + 1] = (uint8_t)follow;
+          }
+        }
+      }
+      run += (p < N) ? cg : 0u;
+    }
+  }
+}
+
+// ---- CRC-32 (bzip2: MSB-first, poly 0x04c11db7, init ~0, final ~) of input [s,e) per block
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b) {        // a*b mod P, bit k = x^k
+  uint32_t r = 0;
+#pragma unroll 4
+  for (int i = 31; i >= 0; i--) {
+    r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r;
+}
+__device__ uint32_t gf_xpow8(uint64_t nbytes) {                              // x^(8*nbytes) mod P
+  uint32_t result = 1u, base = 0x100u;                                       // x^8
+  while (nbytes) {
+    if (nbytes & 1) result = gf_mul(result, base);
+    base = gf_mul(base, base);
+    nbytes >>= 1;
+  }
+  return result;
+}
+constexpr uint32_t CRC_SEG = 16384;   // bytes per workgroup: 256 threads x 64 bytes
+
+__global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict__ in, const RleBlock* __restrict__ blocks,
+                                                       const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
+                                                       uint32_t* __restrict__ seg_crc) {
+  __shared__ uint32_t tab[256];
+  __shared__ uint32_t part[256];
+  const uint32_t k = blockIdx.y;
+  if (k >= *nblocks_p) return;
+  const RleBlock bd = blocks[k];
+  const uint64_t seg_start = bd.s + (uint64_t)blockIdx.x * CRC_SEG;
+  if (seg_start >= bd.e) return;
+  {
+    uint32_t c = (uint32_t)threadIdx.x << 24;
+    for (int i = 0; i < 8; i++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : (c << 1);
+    tab[threadIdx.x] = c;
+  }
+  __syncthreads();
+  const uint64_t a = seg_start + (uint64_t)threadIdx.x * 64;
+  uint64_t bend = a + 64; if (bend > bd.e) bend = bd.e;
+  uint32_t crc = 0;
+  for (uint64_t p = a; p < bend; p++) crc = (crc << 8) ^ tab[((crc >> 24) ^ in[p]) & 0xff];
+  part[threadIdx.x] = crc;
+  __syncthreads();
+  // tree combine: node (t, width w) = combine(left part[t], right part[t+w]) where right covers bytes
+  // [a + 64w, a + 128w) clipped to e
+  for (uint32_t wdt = 1; wdt < 256; wdt <<= 1) {
+    if ((threadIdx.x & (2 * wdt - 1)) == 0) {
+      const uint64_t rstart = seg_start + (uint64_t)(threadIdx.x + wdt) * 64;
+      if (rstart < bd.e) {
+        uint64_t rend = rstart + (uint64_t)wdt * 64; if (rend > bd.e) rend = bd.e;
+        part[threadIdx.x] = gf_mul(part[threadIdx.x], gf_xpow8(rend - rstart)) ^ part[threadIdx.x + wdt];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) seg_crc[(size_t)k * max_segs + blockIdx.x] = part[0];
+}
+
+__global__ void rle_crc_final(const RleBlock* __restrict__ blocks, const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
+                              const uint32_t* __restrict__ seg_crc, uint32_t* __restrict__ block_crc, uint32_t* __restrict__ block_len) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= *nblocks_p) return;
+  const RleBlock bd = blocks[k];
+  const uint64_t n = bd.e - bd.s;
+  uint32_t crc = 0;
+  uint64_t done = 0;
+  const uint32_t xfull = gf_xpow8(CRC_SEG);
+  for (uint32_t sgi = 0; done < n; sgi++) {
+    const uint64_t l = n - done < CRC_SEG ? n - done : CRC_SEG;
+    crc = gf_mul(crc, l == CRC_SEG ? xfull : gf_xpow8(l)) ^ seg_crc[(size_t)k * max_segs + sgi];
+    done += l;
+  }
+  crc ^= gf_mul(0xFFFFFFFFu, gf_xpow8(n));     // init = ~0 carried through n bytes
+  block_crc[k] = ~crc;
+  block_len[k] = bd.len;
+}
+
+// ------------------------------------------------------------------------------------------
+size_t Rle1Work::bytes_needed(size_t max_in, uint32_t cap) {
+  const size_t Tn = (max_in + RT - 1) / RT + 2;
+  const size_t maxb = max_blocks_for(max_in, cap);
+  const size_t segs = max_segs_for(cap);
+  size_t b = 0;
+  auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
+  add(Tn * 8); add(Tn * 8); add((Tn + 1) * 8);
+  add(maxb * sizeof(RleBlock)); add(maxb * 4); add(maxb * 4); add(64);
+  add(maxb * segs * 4);
+  return b + 4096;
+}
+int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_) {
+  max_in = max_in_; cap = cap_;
+  const size_t Tn = (max_in + RT - 1) / RT + 2;
+  max_blocks = (uint32_t)max_blocks_for(max_in, cap);
+  max_segs = (uint32_t)max_segs_for(cap);
+  fb = a.take<uint64_t>(Tn); lb = a.take<uint64_t>(Tn); gt = a.take<uint64_t>(Tn + 1);
+  blocks = a.take<RleBlock>(max_blocks); block_len = a.take<uint32_t>(max_blocks); block_crc = a.take<uint32_t>(max_blocks);
+  nblocks = a.take<uint32_t>(16);
+  seg_crc = a.take<uint32_t>((size_t)max_blocks * max_segs);
+  return seg_crc ? 0 : CJS_E_OUT_OF_MEMORY;
+}
+
+// Runs stage 0 for input d_in[0..N).  d_blocks receives the RLE1 bytes (stride = cap per block).
+// Leaves the number of blocks in w.nblocks[0] (device) and returns it in *nblocks_host (syncs the stream).
+int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint8_t* d_blocks, uint32_t* nblocks_host) {
+  if (N > w.max_in) return CJS_E_INVALID_ARG;
+  if (N == 0) { *nblocks_host = 0; CJS_HIP_TRY(hipMemsetAsync(w.nblocks, 0, 4, s)); return 0; }
+  const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
+  hipLaunchKernelGGL(rle_tile_summary, dim3(Tn), dim3(256), 0, s, d_in, N, w.fb, w.lb);
+  hipLaunchKernelGGL(rle_scan_boundaries, dim3(1), dim3(1024), 0, s, w.fb, w.lb, Tn, N);
+  hipLaunchKernelGGL(rle_tile_count, dim3(Tn), dim3(256), 0, s, d_in, N, w.lb, w.gt);
+  hipLaunchKernelGGL(rle_scan_counts, dim3(1), dim3(1024), 0, s, w.gt, Tn);
+  hipLaunchKernelGGL(rle_walk, dim3(1), dim3(1024), 0, s, d_in, N, w.cap, Tn, w.lb, w.fb, w.gt, w.blocks, w.max_blocks, w.nblocks);
+  hipLaunchKernelGGL(rle_materialize, dim3(Tn), dim3(256), 0, s, d_in, N, w.cap, w.lb, w.fb, w.gt, w.blocks, w.nblocks, d_blocks);
+  hipLaunchKernelGGL(rle_crc_partial, dim3(w.max_segs, w.max_blocks), dim3(256), 0, s, d_in, w.blocks, w.nblocks, w.max_segs, w.seg_crc);
+  hipLaunchKernelGGL(rle_crc_final, dim3((w.max_blocks + 63) / 64), dim3(64), 0, s, w.blocks, w.nblocks, w.max_segs, w.seg_crc, w.block_crc, w.block_len);
+  CJS_HIP_TRY(hipGetLastError());
+  uint32_t* h = nullptr;
+  CJS_HIP_TRY(hipHostMalloc((void**)&h, 16));
+  hipError_t e1 = hipMemcpyAsync(h, w.nblocks, 4, hipMemcpyDeviceToHost, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  *nblocks_host = h[0];
+  (void)hipHostFree(h);
+  if (e1 != hipSuccess || e2 != hipSuccess) return CJS_E_HIP;
+  return 0;
+}
+
+}  // namespace cjs

@@ -51,3 +51,53 @@ BWT_INPUTS = {
 def test_bwt_stage(hip, oracle, name, cyclic):
     data, block_len = BWT_INPUTS[name]
     _check_bwt(hip, oracle, data, block_len, cyclic)
+
+
+RLE_INPUTS = {
+    "empty": ({"kind": "repeat", "unit_hex": "00", "n": 0}, [1, 9]),
+    "one": ({"kind": "repeat", "unit_hex": "41", "n": 1}, [1]),
+    "run4_at_eof": ({"kind": "concat", "parts": [{"kind": "repeat", "unit_hex": "78797a", "n": 3}, {"kind": "repeat", "unit_hex": "71", "n": 4}]}, [9]),
+    "zeros_300000": ({"kind": "repeat", "unit_hex": "00", "n": 300000}, [1, 9]),
+    "zeros_12M": ({"kind": "repeat", "unit_hex": "00", "n": 12000000}, [1]),
+    "ab_250001": ({"kind": "repeat", "unit_hex": "6162", "n": 250001}, [1]),
+    "long_runs_mixed": ({"kind": "concat", "parts": [
+        {"kind": "repeat", "unit_hex": "61", "n": 255}, {"kind": "repeat", "unit_hex": "62", "n": 256},
+        {"kind": "repeat", "unit_hex": "63", "n": 259}, {"kind": "repeat", "unit_hex": "64", "n": 4},
+        {"kind": "repeat", "unit_hex": "65", "n": 5}, {"kind": "repeat", "unit_hex": "66", "n": 1000},
+        {"kind": "repeat", "unit_hex": "67", "n": 3}, {"kind": "repeat", "unit_hex": "61", "n": 260},
+        {"kind": "repeat", "unit_hex": "6162", "n": 9}, {"kind": "repeat", "unit_hex": "00", "n": 511}]}, [1, 9]),
+    "q2_run_at_block_end": ({"kind": "concat", "parts": [
+        {"kind": "xorshift", "n": 99977, "seed": 99, "mask": 63, "add": 32}, {"kind": "repeat", "unit_hex": "00", "n": 4},
+        {"kind": "repeat", "unit_hex": "41", "n": 50}, {"kind": "xorshift", "n": 1000, "seed": 5, "mask": 63, "add": 32}]}, [1]),
+    "q2_count_fills_block": ({"kind": "concat", "parts": [
+        {"kind": "xorshift", "n": 99976, "seed": 98, "mask": 63, "add": 32}, {"kind": "repeat", "unit_hex": "00", "n": 40},
+        {"kind": "xorshift", "n": 1000, "seed": 6, "mask": 63, "add": 32}]}, [1]),
+    "q2_run_crosses_block": ({"kind": "concat", "parts": [
+        {"kind": "xorshift", "n": 99979, "seed": 97, "mask": 63, "add": 32}, {"kind": "repeat", "unit_hex": "7a", "n": 700},
+        {"kind": "xorshift", "n": 500, "seed": 7, "mask": 63, "add": 32}]}, [1]),
+    "exact_block_99981": ({"kind": "repeat", "unit_hex": "6162636465666768696a", "n": 99981}, [1]),
+    "exact_2blocks": ({"kind": "repeat", "unit_hex": "6162636465666768696a6b", "n": 199962}, [1]),
+    "random2sym": ({"kind": "xorshift", "n": 400000, "seed": 4242, "mask": 1, "add": 48}, [1]),
+    "random4sym": ({"kind": "xorshift", "n": 500000, "seed": 777, "mask": 3, "add": 97}, [1, 2]),
+    "textgen_3M": ({"kind": "textgen", "n": 3000000, "seed": 2}, [1, 9]),
+    "sample4": ({"kind": "file", "name": "sample4.ref"}, [1, 3]),
+    "sample2": ({"kind": "file", "name": "sample2.ref"}, [1]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RLE_INPUTS))
+def test_rle1_stage(hip, oracle, name):
+    recipe, levels = RLE_INPUTS[name]
+    data = recipes.build(recipe)
+    for level in levels:
+        want = oracle.rle1_blocks(data, level)
+        rc, got = hip.stage_rle1(data, level)
+        assert rc == 0
+        assert len(got) == len(want), "level %d: %d blocks, want %d" % (level, len(got), len(want))
+        for k, ((gb, gcrc, gs), (wb, wcrc, ws, we)) in enumerate(zip(got, want)):
+            assert gs == ws, "level %d block %d start %d want %d" % (level, k, gs, ws)
+            assert gb.size == wb.size, "level %d block %d len %d want %d" % (level, k, gb.size, wb.size)
+            if not np.array_equal(gb, wb):
+                bad = np.nonzero(gb != wb)[0]
+                raise AssertionError("level %d block %d: %d bytes differ, first at %d" % (level, k, bad.size, bad[0]))
+            assert gcrc == wcrc, "level %d block %d crc %08x want %08x" % (level, k, gcrc, wcrc)
