@@ -1,0 +1,36 @@
+// huff.h — Huffman table construction + bit packing stage buffers and entry points.
+#pragma once
+#include "cjs_internal.h"
+
+namespace cjs {
+
+struct HuffBufs {
+  uint8_t* sel;       // [nb][sel_stride] table index per group of 50 symbols
+  uint8_t* selj;      // [nb][sel_stride] MTF position of each selector (unary-coded in the stream)
+  uint16_t* bcost;    // [nb][sel_stride] cost of each group under its selected table
+  uint8_t* lens;      // [nb][6][258]
+  uint32_t* codes;    // [nb][6][258] canonical codes
+  uint32_t* ngroups;  // [nb]
+  uint32_t* bitlen;   // [nb] bits of the block incl. its 48-bit magic and CRC
+  uint64_t* bitoff;   // [nb+1] absolute bit offset of each block in the output
+  size_t sel_stride;
+};
+
+struct HuffWork {
+  size_t max_blocks = 0;
+  HuffBufs b{};
+  uint64_t* scalars = nullptr;   // [0] total bits, [1] (u32) stream crc
+  static size_t sel_stride_for(uint32_t stride) { return (((size_t)stride + 1 + 49) / 50 + 63) & ~(size_t)63; }
+  static size_t bytes_needed(size_t max_blocks, uint32_t stride);
+  int carve(Arena& a, size_t max_blocks, uint32_t stride);
+};
+
+int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
+                    const uint32_t* d_asz, const uint32_t* d_freq, const uint8_t* d_alist);
+// Packs blocks [first, first+count) starting at absolute bit `start_bit` of d_out32 (which must be zeroed).
+int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first, uint32_t count, uint64_t start_bit, int level,
+                  int write_header, int write_trailer, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
+                  const uint32_t* d_asz, const uint8_t* d_alist, const uint32_t* d_block_crc, const uint32_t* d_pidx,
+                  uint32_t* d_out32);
+
+}  // namespace cjs

@@ -1,0 +1,462 @@
+// huff.hip — bzip2 entropy stage on the GPU: multi-table canonical Huffman construction
+// (the reference's own heuristic, bit-exact), bit-length accounting and bit packing.
+//
+// Replaces J/Bzip2_joined_.js: StaticHuffman ctor :1866-1894 + HuffmanAllocator :1085-1301,
+// assignSelectors :1989-2004, optimizeHuffmanGroups :2005-2054, table count :2150-2163,
+// selector MTF/unary :2167-2182, StaticHuffman.emit/computeCanonical/encode :1896-1951,
+// data loop :2189-2194, BitStream.writeBits :154-166.
+// One workgroup per block: the work is tiny (<= 18 k groups of 50 symbols, <= 6 tables of <= 258
+// symbols) but its logic is serial, so tables are built one per wave (rank sort by the wave,
+// in-place length-limited allocator on lane 0 with the node array in LDS) and everything that is
+// per-group or per-symbol is data-parallel across the 1024 lanes.  Bit packing: wave prefix-scan of
+// code lengths -> bit offsets -> words assembled in LDS -> coalesced big-endian stores.
+#include "cjs_internal.h"
+#include "prims.hpp"
+#include "huff.h"
+
+namespace cjs {
+
+constexpr int MAXSYM = 258;
+constexpr int MAX_BITS = 20;
+constexpr int GSZ = 50;
+
+// ------------------------------------------------------------------ allocator (lane 0, LDS array)
+__device__ int ha_first(const int* a, int len, int i, int nodes_to_move) {          // Bzip2:1135-1156
+  const int limit = i;
+  int k = len - 2;
+  while (i >= nodes_to_move && (a[i] % len) > limit) { k = i; i -= (limit - i + 1); }
+  if (i < nodes_to_move - 1) i = nodes_to_move - 1;
+  while (k > i + 1) {
+    const int mid = (i + k) >> 1;
+    if ((a[mid] % len) > limit) k = mid; else i = mid;
+  }
+  return k;
+}
+__device__ void ha_alloc(int* a, int len, int maxlen) {                             // Bzip2:1275-1298
+  if (len == 2) { a[1] = 1; a[0] = 1; return; }
+  if (len == 1) { a[0] = 1; return; }
+  // pass 1: extended parent pointers (Bzip2:1162-1186)
+  a[0] += a[1];
+  {
+    int head = 0, top = 2;
+    for (int tail = 1; tail < len - 1; tail++) {
+      int w;
+      if (top >= len || a[head] < a[top]) { w = a[head]; a[head++] = tail; }
+      else w = a[top++];
+      if (top >= len || (head < tail && a[head] < a[top])) { w += a[head]; a[head++] = tail + len; }
+      else w += a[top++];
+      a[tail] = w;
+    }
+  }
+  // pass 2: nodes to relocate (Bzip2:1195-1204)
+  int reloc = len - 2;
+  for (int depth = 1; depth < maxlen - 1 && reloc > 1; depth++) reloc = ha_first(a, len, reloc - 1, 0);
+  // pass 3
+  if ((a[0] % len) >= reloc) {                                                      // Bzip2:1211-1226
+    int first = len - 2, next = len - 1;
+    for (int depth = 1, avail = 2; avail > 0; depth++) {
+      const int last = first;
+      first = ha_first(a, len, last - 1, 0);
+      for (int i = avail - (last - first); i > 0; i--) a[next--] = depth;
+      avail = (last - first) << 1;
+    }
+  } else {                                                                          // Bzip2:1235-1264
+    const unsigned rm1 = (unsigned)(reloc - 1);
+    const int insert_depth = maxlen - (rm1 ? 32 - __builtin_clz(rm1) : 0);      // Util.fls
+    int first = len - 2, next = len - 1;
+    int depth = insert_depth == 1 ? 2 : 1;
+    int left = insert_depth == 1 ? reloc - 2 : reloc;
+    for (int avail = depth << 1; avail > 0; depth++) {
+      const int last = first;
+      first = first <= reloc ? first : ha_first(a, len, last - 1, reloc);
+      int offset = 0;
+      if (depth >= insert_depth) { offset = 1 << (depth - insert_depth); if (left < offset) offset = left; }
+      else if (depth == insert_depth - 1) { offset = 1; if (a[first] == last) first++; }
+      for (int i = avail - (last - first + offset); i > 0; i--) a[next--] = depth;
+      left -= offset;
+      avail = (last - first + offset) << 1;
+    }
+  }
+}
+
+// One wave builds one table: freq[0..n) -> lens[0..n).  key/work are per-table LDS scratch (n entries).
+__device__ void build_table_wave(const uint32_t* freq, uint8_t* lens, uint32_t* key, int* work, int n) {
+  const int lane = lane_id();
+  for (int i = lane; i < n; i += 64) key[i] = (freq[i] << 9) | (uint32_t)i;       // Bzip2:1881-1883
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  int rk[5];
+  for (int t = 0, i = lane; t < 5; t++, i += 64) {
+    rk[t] = 0;
+    if (i < n) { const uint32_t ki = key[i]; int r = 0; for (int k = 0; k < n; k++) r += key[k] < ki; rk[t] = r; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int t = 0, i = lane; t < 5; t++, i += 64) if (i < n) work[rk[t]] = (int)(freq[i]);   // sortedFreq
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (lane == 0) ha_alloc(work, n, MAX_BITS);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  for (int t = 0, i = lane; t < 5; t++, i += 64) if (i < n) lens[i] = (uint8_t)work[rk[t]];
+}
+
+struct HuffShared {
+  uint32_t freq[6][260];
+  uint32_t key[6][260];
+  int work[6][260];
+  uint8_t lens[6][264];
+  uint32_t chist[1024];
+  uint32_t counts[8];
+  uint32_t misc[8];
+  uint32_t sm[16];
+};
+
+__device__ void assign_selectors(const HuffShared& S, const uint16_t* __restrict__ A, uint32_t npos, uint32_t nsel, int ng,
+                                 uint8_t* __restrict__ sel, uint16_t* __restrict__ bcost) {
+  for (uint32_t g = threadIdx.x; g < nsel; g += 1024) {                             // Bzip2:1989-2004
+    const uint32_t off = g * GSZ, cnt = npos - off < GSZ ? npos - off : GSZ;
+    uint32_t c[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < cnt; i++) {
+      const uint32_t s = A[off + i];
+#pragma unroll
+      for (int j = 0; j < 6; j++) if (j < ng) c[j] += S.lens[j][s];
+    }
+    int best = 0; uint32_t bc = c[0];
+#pragma unroll
+    for (int j = 1; j < 6; j++) if (j < ng && c[j] < bc) { best = j; bc = c[j]; }
+    sel[g] = (uint8_t)best; bcost[g] = (uint16_t)bc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride,
+                                                   const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
+                                                   const uint32_t* __restrict__ freq_all, const uint8_t* __restrict__ alist_all) {
+  __shared__ HuffShared S;
+  const uint32_t blk = blockIdx.x;
+  const uint32_t npos = npos_all[blk], asz = asz_all[blk];
+  const int n = (int)asz + 2;
+  const uint16_t* A = Aall + (size_t)blk * a_stride;
+  uint8_t* sel = hb.sel + (size_t)blk * hb.sel_stride;
+  uint8_t* selj = hb.selj + (size_t)blk * hb.sel_stride;
+  uint16_t* bcost = hb.bcost + (size_t)blk * hb.sel_stride;
+  const uint32_t nsel = (npos + GSZ - 1) / GSZ;
+  const int target = npos >= 2400 ? 6 : npos >= 1200 ? 5 : npos >= 600 ? 4 : npos >= 200 ? 3 : 2;   // Bzip2:2150
+  const int w = wave_id();
+
+  // initial tables: global frequencies and flat (Bzip2:2155-2157)
+  for (int i = threadIdx.x; i < n; i += 1024) { S.freq[0][i] = freq_all[(size_t)blk * 258 + i]; S.freq[1][i] = 1; }
+  __syncthreads();
+  if (w < 2) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
+  __syncthreads();
+  int ng = 2;
+  while (ng < target) {                                                             // Bzip2:2012-2053
+    assign_selectors(S, A, npos, nsel, ng, sel, bcost);
+    if (threadIdx.x < 8) S.counts[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < nsel; g += 1024) atomicAdd(&S.counts[sel[g]], 1u);
+    S.chist[threadIdx.x] = 0;
+    __syncthreads();
+    int which = 0;
+    for (int j = 1; j < ng; j++) if (S.counts[j] > S.counts[which]) which = j;      // indexOf(max): first
+    const uint32_t nsp = S.counts[which], m = nsp >> 1;
+    for (uint32_t g = threadIdx.x; g < nsel; g += 1024) if (sel[g] == which) atomicAdd(&S.chist[bcost[g] & 1023u], 1u);
+    __syncthreads();
+    {
+      const uint32_t hv = S.chist[threadIdx.x];
+      uint32_t tot;
+      const uint32_t cum = block_excl_sum<1024>(hv, S.sm, tot);
+      if (hv && cum <= m && m < cum + hv) { S.misc[0] = threadIdx.x; S.misc[1] = cum; }
+      __syncthreads();
+    }
+    const uint32_t cstar = S.misc[0], cumstar = S.misc[1];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nsel; base += 1024) {        // stable order inside the median cost bin (Q16)
+      const uint32_t g = base + threadIdx.x;
+      uint32_t f = 0, mine = 0xFFFFu;
+      if (g < nsel && sel[g] == which) { mine = bcost[g]; f = mine == cstar; }
+      uint32_t tot;
+      const uint32_t ex = block_excl_sum<1024>(f, S.sm, tot);
+      if (g < nsel && mine != 0xFFFFu) {
+        if (mine > cstar || (f && cumstar + carry + ex >= m)) sel[g] = (uint8_t)ng;
+      }
+      carry += tot;
+    }
+    ng++;
+    for (int i = threadIdx.x; i < 6 * 260; i += 1024) (&S.freq[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < npos; i += 1024) atomicAdd(&S.freq[sel[i / GSZ]][A[i]], 1u);   // Bzip2:2043-2048
+    __syncthreads();
+    if (w < ng) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
+    __syncthreads();
+  }
+  assign_selectors(S, A, npos, nsel, ng, sel, bcost);                               // Bzip2:2163
+  __syncthreads();
+
+  // ---- bit accounting
+  uint32_t data_bits = 0;
+  for (uint32_t g = threadIdx.x; g < nsel; g += 1024) data_bits += bcost[g];
+  data_bits = block_sum<1024>(data_bits, S.sm);
+  // selector MTF positions (Bzip2:2170-2182): j = #values more recent than the previous occurrence
+  uint32_t sel_bits = 0;
+  {
+    uint32_t lastc[6] = {0, 0, 0, 0, 0, 0};                   // (last index+1) of each value in earlier tiles
+    for (uint32_t base = 0; base < nsel; base += 1024) {
+      const uint32_t g = base + threadIdx.x;
+      const uint32_t sv = g < nsel ? sel[g] : 255u;
+      uint32_t lastv[6];
+#pragma unroll
+      for (int v = 0; v < 6; v++) {
+        const uint32_t mine = sv == (uint32_t)v ? g + 1 : 0u;
+        const uint32_t im = block_incl_max<1024>(mine, S.sm);
+        S.chist[threadIdx.x] = im;
+        __syncthreads();
+        const uint32_t ex = threadIdx.x ? S.chist[threadIdx.x - 1] : 0u;
+        const uint32_t tmax = S.chist[1023];
+        __syncthreads();
+        lastv[v] = ex > lastc[v] ? ex : lastc[v];
+        lastc[v] = tmax > lastc[v] ? tmax : lastc[v];
+      }
+      if (g < nsel) {
+        uint32_t j = 0, mylast = 0;
+#pragma unroll
+        for (int v = 0; v < 6; v++) if ((uint32_t)v == sv) mylast = lastv[v];
+#pragma unroll
+        for (int v = 0; v < 6; v++) {
+          if (v >= ng || (uint32_t)v == sv) continue;
+          if (mylast) j += lastv[v] > mylast;                 // seen before: values touched since then
+          else j += (lastv[v] != 0) || ((uint32_t)v < sv);    // first use: seen values + unseen smaller ones
+        }
+        selj[g] = (uint8_t)j;
+        sel_bits += j + 1;
+      }
+    }
+  }
+  sel_bits = block_sum<1024>(sel_bits, S.sm);
+  uint32_t tab_bits = 0;
+  for (int i = threadIdx.x; i < ng * n; i += 1024) {                                // Bzip2:1926-1947
+    const int t = i / n, s = i - t * n;
+    const int cur = S.lens[t][s], prev = s ? S.lens[t][s - 1] : cur;
+    tab_bits += 2u * (uint32_t)(cur > prev ? cur - prev : prev - cur) + 1u + (s == 0 ? 5u : 0u);
+  }
+  tab_bits = block_sum<1024>(tab_bits, S.sm);
+  // used map: 16 + 16 per non-empty range (Bzip2:2071-2080)
+  if (threadIdx.x < 8) S.counts[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < asz) atomicOr(&S.counts[0], 1u << (alist_all[(size_t)blk * 256 + threadIdx.x] >> 4));
+  __syncthreads();
+  const uint32_t nranges = (uint32_t)__builtin_popcount(S.counts[0]);
+  // canonical codes (Bzip2:1896-1916): code = first_code[len] + #{smaller symbols with the same len}
+  uint8_t* glens = hb.lens + (size_t)blk * 6 * MAXSYM;
+  uint32_t* gcodes = hb.codes + (size_t)blk * 6 * MAXSYM;
+  for (int i = threadIdx.x; i < 6 * 32; i += 1024) (&S.key[0][0])[i] = 0;           // reuse key[] as len histograms [6][32]
+  __syncthreads();
+  uint32_t* lhist = &S.key[0][0];
+  for (int i = threadIdx.x; i < ng * n; i += 1024) { const int t = i / n, s = i - t * n; atomicAdd(&lhist[t * 32 + S.lens[t][s]], 1u); }
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)ng) {
+    uint32_t* fc = (uint32_t*)&S.work[0][0] + threadIdx.x * 32;                     // first_code per length
+    uint32_t code = 0;
+    for (int l = 1; l <= MAX_BITS; l++) { code <<= 1; fc[l] = code; code += lhist[threadIdx.x * 32 + l]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ng * n; i += 1024) {
+    const int t = i / n, s = i - t * n;
+    const int l = S.lens[t][s];
+    uint32_t r = 0;
+    for (int k = 0; k < s; k++) r += S.lens[t][k] == l;
+    gcodes[t * MAXSYM + s] = ((const uint32_t*)&S.work[0][0])[t * 32 + l] + r;
+    glens[t * MAXSYM + s] = (uint8_t)l;
+  }
+  if (threadIdx.x == 0) {
+    hb.ngroups[blk] = (uint32_t)ng;
+    hb.bitlen[blk] = 80u + 25u + 16u + 16u * nranges + 18u + sel_bits + tab_bits + data_bits;
+  }
+}
+
+// ------------------------------------------------------------------ bit offsets + stream CRC (one lane, tiny)
+__global__ void huff_offsets(HuffBufs hb, const uint32_t* __restrict__ block_crc, uint32_t nb, uint32_t first, uint32_t count,
+                             uint64_t start_bit, uint32_t* __restrict__ stream_crc_out) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint64_t bit = start_bit;
+  for (uint32_t k = first; k < first + count; k++) { hb.bitoff[k] = bit; bit += hb.bitlen[k]; }
+  hb.bitoff[first + count] = bit;
+  uint32_t c = 0;
+  for (uint32_t k = 0; k < nb; k++) c = ((c << 1) | (c >> 31)) ^ block_crc[k];      // Bzip2:2237
+  *stream_crc_out = c;
+}
+
+// ------------------------------------------------------------------ bit packing
+// Put `nbits` (<= 64) of `val` at absolute stream bit `bit` into LDS words indexed from word0.
+__device__ __forceinline__ void put_bits(uint32_t* words, uint64_t word0, uint64_t bit, uint64_t val, uint32_t nbits) {
+  if (!nbits) return;
+  uint64_t w = (bit >> 5) - word0;
+  uint32_t o = (uint32_t)(bit & 31);
+  uint32_t left = nbits;
+  while (left) {
+    const uint32_t room = 32 - o, take = left < room ? left : room;
+    const uint32_t chunk = (uint32_t)((val >> (left - take)) & (take == 32 ? 0xFFFFFFFFull : ((1ull << take) - 1ull)));
+    atomicOr(&words[w], chunk << (room - take));
+    left -= take; o = 0; w++;
+  }
+}
+
+constexpr int PK_ITEMS = 4;                       // items per thread per tile
+constexpr int PK_WORDS = (1024 * PK_ITEMS * 40) / 32 + 8;
+
+struct Item { uint64_t val; uint32_t nbits; };
+
+template <typename F>
+__device__ void pack_phase(uint32_t count, F item_fn, uint32_t* words, uint32_t* sm, uint64_t& bit, uint32_t* __restrict__ out32) {
+  for (uint32_t base = 0; base < count; base += 1024 * PK_ITEMS) {
+    Item it[PK_ITEMS];
+    uint32_t nb = 0;
+#pragma unroll
+    for (int j = 0; j < PK_ITEMS; j++) {
+      const uint32_t i = base + threadIdx.x * PK_ITEMS + j;
+      it[j].val = 0; it[j].nbits = 0;
+      if (i < count) it[j] = item_fn(i);
+      nb += it[j].nbits;
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_sum<1024>(nb, sm, tot);
+    const uint64_t word0 = bit >> 5;
+    const uint32_t nwords = (uint32_t)(((bit + tot + 31) >> 5) - word0);
+    for (uint32_t i = threadIdx.x; i < nwords; i += 1024) words[i] = 0;
+    __syncthreads();
+    uint64_t b = bit + ex;
+#pragma unroll
+    for (int j = 0; j < PK_ITEMS; j++) { put_bits(words, word0, b, it[j].val, it[j].nbits); b += it[j].nbits; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nwords; i += 1024) {
+      const uint32_t v = __builtin_bswap32(words[i]);
+      if (i == 0 || i == nwords - 1) { if (v) atomicOr(&out32[word0 + i], v); }
+      else out32[word0 + i] = v;
+    }
+    __syncthreads();
+    bit += tot;
+  }
+}
+
+__global__ __launch_bounds__(1024) void pack_block(HuffBufs hb, uint32_t first, const uint16_t* __restrict__ Aall, size_t a_stride,
+                                                   const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
+                                                   const uint8_t* __restrict__ alist_all, const uint32_t* __restrict__ block_crc,
+                                                   const uint32_t* __restrict__ pidx_all, uint32_t* __restrict__ out32) {
+  __shared__ uint32_t words[PK_WORDS];
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t used16[17];
+  __shared__ uint32_t ctab[6 * MAXSYM];
+  __shared__ uint8_t ltab[6 * MAXSYM + 4];
+  const uint32_t blk = first + blockIdx.x;
+  const uint32_t npos = npos_all[blk], asz = asz_all[blk], ng = hb.ngroups[blk];
+  const uint32_t n = asz + 2, nsel = (npos + GSZ - 1) / GSZ;
+  const uint16_t* A = Aall + (size_t)blk * a_stride;
+  const uint8_t* sel = hb.sel + (size_t)blk * hb.sel_stride;
+  const uint8_t* selj = hb.selj + (size_t)blk * hb.sel_stride;
+  for (uint32_t i = threadIdx.x; i < 6 * MAXSYM; i += 1024) { ctab[i] = hb.codes[(size_t)blk * 6 * MAXSYM + i]; ltab[i] = hb.lens[(size_t)blk * 6 * MAXSYM + i]; }
+  if (threadIdx.x < 17) used16[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < asz) {
+    const uint32_t v = alist_all[(size_t)blk * 256 + threadIdx.x];
+    atomicOr(&used16[1 + (v >> 4)], 0x8000u >> (v & 15));
+    atomicOr(&used16[0], 0x8000u >> (v >> 4));
+  }
+  __syncthreads();
+  uint64_t bit = hb.bitoff[blk];
+  const uint32_t crc = block_crc[blk], pidx = pidx_all[blk];
+  // header: magic(48) crc(32) rand(1)+pidx(24) coarse(16) fine(16 each) ngroups(3)+nsel(15)
+  const uint32_t coarse = used16[0];
+  pack_phase(22, [&](uint32_t i) -> Item {
+    if (i == 0) return Item{0x314159265359ull, 48};
+    if (i == 1) return Item{crc, 32};
+    if (i == 2) return Item{pidx & 0xFFFFFFu, 25};
+    if (i == 3) return Item{coarse, 16};
+    if (i < 20) { const uint32_t r = i - 4; return (coarse & (0x8000u >> r)) ? Item{used16[1 + r], 16} : Item{0, 0}; }
+    if (i == 20) return Item{((uint64_t)ng << 15) | nsel, 18};
+    return Item{0, 0};
+  }, words, sm, bit, out32);
+  // selectors, MTF + unary (Bzip2:2171-2182)
+  pack_phase(nsel, [&](uint32_t g) -> Item { const uint32_t j = selj[g]; return Item{((1ull << j) - 1ull) << 1, j + 1}; }, words, sm, bit, out32);
+  // tables (Bzip2:1926-1947)
+  pack_phase(ng * n, [&](uint32_t i) -> Item {
+    const uint32_t t = i / n, s = i - t * n;
+    const uint32_t cur = ltab[t * MAXSYM + s], prev = s ? ltab[t * MAXSYM + s - 1] : cur;
+    const uint32_t d = cur > prev ? cur - prev : prev - cur;
+    uint64_t v = 0;
+    const uint64_t pat = cur > prev ? 2ull : 3ull;
+    for (uint32_t k = 0; k < d; k++) v = (v << 2) | pat;
+    v <<= 1;
+    uint32_t nbits = 2 * d + 1;
+    if (s == 0) { v |= (uint64_t)cur << 1; nbits = 6; }      // 5-bit start length, then '0'
+    return Item{v, nbits};
+  }, words, sm, bit, out32);
+  // data (Bzip2:2189-2194)
+  pack_phase(npos, [&](uint32_t i) -> Item {
+    const uint32_t t = sel[i / GSZ], s = A[i];
+    return Item{ctab[t * MAXSYM + s], ltab[t * MAXSYM + s]};
+  }, words, sm, bit, out32);
+}
+
+// stream header / trailer.  One lane.
+__global__ void pack_frame(HuffBufs hb, uint32_t nb_range_end, int level, int write_header, int write_trailer,
+                           const uint32_t* __restrict__ stream_crc, uint32_t* __restrict__ out32, uint64_t* __restrict__ total_bits) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (write_header) atomicOr(&out32[0], __builtin_bswap32(0x425a6830u + (uint32_t)level));   // 'B''Z''h''0'+level
+  uint64_t bit = hb.bitoff[nb_range_end];
+  if (write_trailer) {
+    const uint64_t vals[2] = {0x177245385090ull, (uint64_t)*stream_crc};
+    const uint32_t nbs[2] = {48, 32};
+    for (int q = 0; q < 2; q++) {
+      uint32_t left = nbs[q];
+      while (left) {
+        const uint32_t o = (uint32_t)(bit & 31), room = 32 - o, take = left < room ? left : room;
+        const uint32_t chunk = (uint32_t)((vals[q] >> (left - take)) & (take == 32 ? 0xFFFFFFFFull : ((1ull << take) - 1ull)));
+        atomicOr(&out32[bit >> 5], __builtin_bswap32(chunk << (room - take)));
+        left -= take; bit += take;
+      }
+    }
+  }
+  *total_bits = bit;
+}
+
+// ------------------------------------------------------------------------------------------
+size_t HuffWork::bytes_needed(size_t max_blocks, uint32_t stride) {
+  size_t b = 0;
+  auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
+  const size_t ss = sel_stride_for(stride);
+  add(max_blocks * ss); add(max_blocks * ss); add(max_blocks * ss * 2);
+  add(max_blocks * 6 * MAXSYM); add(max_blocks * 6 * MAXSYM * 4);
+  add(max_blocks * 4); add(max_blocks * 4); add((max_blocks + 1) * 8); add(64);
+  return b + 4096;
+}
+int HuffWork::carve(Arena& a, size_t max_blocks_, uint32_t stride) {
+  max_blocks = max_blocks_;
+  b.sel_stride = sel_stride_for(stride);
+  b.sel = a.take<uint8_t>(max_blocks * b.sel_stride); b.selj = a.take<uint8_t>(max_blocks * b.sel_stride);
+  b.bcost = a.take<uint16_t>(max_blocks * b.sel_stride);
+  b.lens = a.take<uint8_t>(max_blocks * 6 * MAXSYM); b.codes = a.take<uint32_t>(max_blocks * 6 * MAXSYM);
+  b.ngroups = a.take<uint32_t>(max_blocks); b.bitlen = a.take<uint32_t>(max_blocks); b.bitoff = a.take<uint64_t>(max_blocks + 1);
+  scalars = a.take<uint64_t>(8);
+  return scalars ? 0 : CJS_E_OUT_OF_MEMORY;
+}
+
+int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
+                    const uint32_t* d_asz, const uint32_t* d_freq, const uint8_t* d_alist) {
+  if (nb == 0) return 0;
+  hipLaunchKernelGGL(huff_block, dim3(nb), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_asz, d_freq, d_alist);
+  CJS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first, uint32_t count, uint64_t start_bit, int level,
+                  int write_header, int write_trailer, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
+                  const uint32_t* d_asz, const uint8_t* d_alist, const uint32_t* d_block_crc, const uint32_t* d_pidx,
+                  uint32_t* d_out32) {
+  uint32_t* stream_crc = (uint32_t*)(w.scalars + 1);
+  hipLaunchKernelGGL(huff_offsets, dim3(1), dim3(1), 0, s, w.b, d_block_crc, nb_total, first, count, start_bit, stream_crc);
+  if (count) hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32);
+  hipLaunchKernelGGL(pack_frame, dim3(1), dim3(1), 0, s, w.b, first + count, level, write_header, write_trailer, stream_crc, d_out32, w.scalars);
+  CJS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace cjs

@@ -1,0 +1,32 @@
+// mtf.h — MTF / RLE2 stage buffers (per block, stride-addressed) and entry point.
+#pragma once
+#include "cjs_internal.h"
+
+namespace cjs {
+
+struct MtfBufs {
+  uint32_t* hpos;     // [nb][stride]  run-head positions in U
+  uint8_t* hsym;      // [nb][stride]  run-head symbols
+  uint8_t* hrank;     // [nb][stride]  MTF rank of each head
+  uint8_t* lists;     // [nb][list_stride] MTF list at the start of every 256-head chunk
+  uint16_t* A;        // [nb][a_stride] MTF/RLE2 symbols incl. EOB
+  uint32_t* freq;     // [nb][258]
+  uint8_t* alist;     // [nb][256] used byte values, ascending
+  uint32_t *asz, *nheads, *npos;   // [nb]
+  size_t list_stride, a_stride;
+};
+
+struct MtfWork {
+  size_t max_blocks = 0;
+  uint32_t stride = 0;
+  MtfBufs b{};
+  static size_t list_stride_for(uint32_t stride) { return ((size_t)(stride + 255) / 256 + 1) * 256; }
+  static size_t a_stride_for(uint32_t stride) { return ((size_t)stride + 2 + 7) & ~(size_t)7; }
+  static size_t bytes_needed(size_t max_blocks, uint32_t stride);
+  int carve(Arena& a, size_t max_blocks, uint32_t stride);
+};
+
+// d_U: BWT bytes, block k at k*stride with length d_blen[k]
+int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const uint32_t* d_blen);
+
+}  // namespace cjs

@@ -1,0 +1,204 @@
+// mtf.hip — symbol map, move-to-front and RLE2 (RUNA/RUNB) of the BWT output, plus symbol histogram.
+//
+// Replaces J/Bzip2_joined_.js:2064-2139 (used map, inline MTF with O(n*|alphabet|) search, zero-run
+// coding, freq[]).  The reference walks U serially.  Parallel formulation:
+//   * only RUN HEADS of U (U[p] != U[p-1]) can have a non-zero MTF rank; inside a run the rank is 0.
+//     So: compact the heads (position, symbol), MTF only over the heads, and derive the RLE2 symbols
+//     of each (head, run length) pair locally: [rank+1] followed by the bijective base-2 digits of
+//     (run length - 1).
+//   * MTF over heads is chunked (256 heads per chunk).  The list at a chunk start is "symbols ordered
+//     by last occurrence before the chunk" = a rank-by-counting over <=256 keys, produced by one
+//     workgroup per block that walks the chunks; the chunks are then replayed independently, one lane
+//     per chunk with its list in LDS (padded rows, no bank aliasing between lanes).
+#include "cjs_internal.h"
+#include "prims.hpp"
+#include "mtf.h"
+
+namespace cjs {
+
+constexpr int MTF_CHUNK = 256;
+
+// ---- A: used-symbol list + run-head compaction.  One workgroup per block.
+__global__ __launch_bounds__(1024) void mtf_heads(const uint8_t* __restrict__ U, uint32_t stride, const uint32_t* __restrict__ blen,
+                                                  MtfBufs mb) {
+  __shared__ uint32_t used[256];
+  __shared__ uint32_t sm[16];
+  const uint32_t blk = blockIdx.x, n = blen[blk];
+  const uint8_t* u = U + (size_t)blk * stride;
+  if (threadIdx.x < 256) used[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) used[u[i]] = 1;
+  __syncthreads();
+  {
+    uint32_t f = threadIdx.x < 256 ? used[threadIdx.x] : 0u, tot;
+    const uint32_t ex = block_excl_sum<1024>(f, sm, tot);
+    if (f) mb.alist[(size_t)blk * 256 + ex] = (uint8_t)threadIdx.x;
+    if (threadIdx.x == 0) mb.asz[blk] = tot;
+  }
+  uint32_t* hpos = mb.hpos + (size_t)blk * stride;
+  uint8_t* hsym = mb.hsym + (size_t)blk * stride;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += 4096) {
+    const uint32_t p0 = base + threadIdx.x * 4;
+    uint8_t c[4]; uint32_t fm = 0, cnt = 0;
+    uint8_t prev = (p0 > 0 && p0 - 1 < n) ? u[p0 - 1] : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t p = p0 + j;
+      c[j] = p < n ? u[p] : 0;
+      if (p < n && (p == 0 || c[j] != prev)) { fm |= 1u << j; cnt++; }
+      prev = c[j];
+    }
+    uint32_t tot;
+    uint32_t o = carry + block_excl_sum<1024>(cnt, sm, tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) if ((fm >> j) & 1u) { hpos[o] = p0 + j; hsym[o] = c[j]; o++; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) mb.nheads[blk] = carry;
+}
+
+// ---- C1: MTF list at the start of every chunk of 256 heads.  One workgroup per block, serial over chunks.
+__global__ __launch_bounds__(1024) void mtf_chunk_lists(uint32_t stride, MtfBufs mb) {
+  __shared__ int keys[256];
+  __shared__ uint32_t part[4][256];
+  const uint32_t blk = blockIdx.x, H = mb.nheads[blk], asz = mb.asz[blk];
+  const uint8_t* hsym = mb.hsym + (size_t)blk * stride;
+  uint8_t* lists = mb.lists + (size_t)blk * mb.list_stride;
+  if (threadIdx.x < 256) keys[threadIdx.x] = -1000;
+  __syncthreads();
+  if (threadIdx.x < asz) { const int d = mb.alist[(size_t)blk * 256 + threadIdx.x]; keys[d] = 255 - d; }
+  __syncthreads();
+  const uint32_t nch = (H + MTF_CHUNK - 1) / MTF_CHUNK;
+  const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+  for (uint32_t c = 0; c < nch; c++) {
+    const int kd = keys[d];
+    uint32_t cnt = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) cnt += keys[q * 64 + j] > kd;
+    part[q][d] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 256 && kd >= 0) {
+      const uint32_t p = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+      lists[(size_t)c * 256 + p] = (uint8_t)d;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const uint32_t h = c * MTF_CHUNK + threadIdx.x;
+      if (h < H) atomicMax(&keys[hsym[h]], (int)(256 + h));
+    }
+    __syncthreads();
+  }
+}
+
+// ---- C2: replay each chunk from its start list; one lane per chunk, list in LDS (row stride 260 B)
+constexpr int LROW = 260;
+__global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
+  __shared__ uint8_t L[256 * LROW];
+  const uint32_t blk = blockIdx.y, H = mb.nheads[blk], asz = mb.asz[blk];
+  const uint32_t nch = (H + MTF_CHUNK - 1) / MTF_CHUNK;
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= nch) return;
+  if (c >= nch) return;
+  const uint8_t* hsym = mb.hsym + (size_t)blk * stride;
+  uint8_t* hrank = mb.hrank + (size_t)blk * stride;
+  const uint8_t* lst = mb.lists + (size_t)blk * mb.list_stride + (size_t)c * 256;
+  uint8_t* my = L + threadIdx.x * LROW;
+  for (uint32_t j = 0; j < asz; j++) my[j] = lst[j];
+  const uint32_t h0 = c * MTF_CHUNK, h1 = h0 + MTF_CHUNK < H ? h0 + MTF_CHUNK : H;
+  for (uint32_t h = h0; h < h1; h++) {
+    const uint8_t s = hsym[h];
+    uint8_t prev = my[0];
+    uint32_t r = 0;
+    if (prev != s) {
+      my[0] = s;
+      for (r = 1; r < asz; r++) {
+        const uint8_t x = my[r];
+        my[r] = prev;
+        prev = x;
+        if (x == s) break;
+      }
+    }
+    hrank[h] = (uint8_t)r;
+  }
+}
+
+// ---- D: RLE2 symbols + histogram.  One workgroup per block.
+__global__ __launch_bounds__(1024) void mtf_emit(uint32_t stride, const uint32_t* __restrict__ blen, MtfBufs mb) {
+  __shared__ uint32_t freq[258];
+  __shared__ uint32_t sm[16];
+  const uint32_t blk = blockIdx.x, n = blen[blk], H = mb.nheads[blk], asz = mb.asz[blk];
+  const uint32_t* hpos = mb.hpos + (size_t)blk * stride;
+  const uint8_t* hrank = mb.hrank + (size_t)blk * stride;
+  uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
+  for (int i = threadIdx.x; i < 258; i += 1024) freq[i] = 0;
+  __syncthreads();
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < H; base += 4096) {
+    const uint32_t h0 = base + threadIdx.x * 4;
+    uint32_t lit[4], z[4], nd[4], cnt = 0, rk[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t h = h0 + j;
+      lit[j] = z[j] = nd[j] = rk[j] = 0;
+      if (h < H) {
+        const uint32_t r = hrank[h];
+        const uint32_t len = (h + 1 < H ? hpos[h + 1] : n) - hpos[h];
+        lit[j] = r != 0;
+        rk[j] = r;
+        z[j] = len - lit[j];
+        nd[j] = z[j] ? 31u - (uint32_t)__builtin_clz(z[j] + 1u) : 0u;
+        cnt += lit[j] + nd[j];
+      }
+    }
+    uint32_t tot;
+    uint32_t o = carry + block_excl_sum<1024>(cnt, sm, tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (lit[j]) { A[o++] = (uint16_t)(rk[j] + 1); atomicAdd(&freq[rk[j] + 1], 1u); }
+      const uint32_t v = z[j] + 1u;
+      uint32_t nb1 = 0;
+      for (uint32_t i = 0; i < nd[j]; i++) { const uint32_t bit = (v >> i) & 1u; A[o++] = (uint16_t)bit; nb1 += bit; }
+      if (nd[j]) { if (nb1) atomicAdd(&freq[1], nb1); if (nd[j] - nb1) atomicAdd(&freq[0], nd[j] - nb1); }
+    }
+    carry += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { A[carry] = (uint16_t)(asz + 1); freq[asz + 1] = 1; mb.npos[blk] = carry + 1; }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 258; i += 1024) mb.freq[(size_t)blk * 258 + i] = i < asz + 2 ? freq[i] : 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+size_t MtfWork::bytes_needed(size_t max_blocks, uint32_t stride) {
+  size_t b = 0;
+  auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
+  const size_t ls = list_stride_for(stride), as = a_stride_for(stride);
+  add(max_blocks * stride * 4); add(max_blocks * stride); add(max_blocks * stride); add(max_blocks * ls);
+  add(max_blocks * as * 2); add(max_blocks * 258 * 4); add(max_blocks * 256);
+  add(max_blocks * 4); add(max_blocks * 4); add(max_blocks * 4);
+  return b + 4096;
+}
+int MtfWork::carve(Arena& a, size_t max_blocks_, uint32_t stride_) {
+  max_blocks = max_blocks_; stride = stride_;
+  b.list_stride = list_stride_for(stride); b.a_stride = a_stride_for(stride);
+  b.hpos = a.take<uint32_t>(max_blocks * stride); b.hsym = a.take<uint8_t>(max_blocks * stride); b.hrank = a.take<uint8_t>(max_blocks * stride);
+  b.lists = a.take<uint8_t>(max_blocks * b.list_stride);
+  b.A = a.take<uint16_t>(max_blocks * b.a_stride); b.freq = a.take<uint32_t>(max_blocks * 258); b.alist = a.take<uint8_t>(max_blocks * 256);
+  b.asz = a.take<uint32_t>(max_blocks); b.nheads = a.take<uint32_t>(max_blocks); b.npos = a.take<uint32_t>(max_blocks);
+  return b.npos ? 0 : CJS_E_OUT_OF_MEMORY;
+}
+
+int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const uint32_t* d_blen) {
+  if (nb == 0) return 0;
+  if (nb > w.max_blocks) return CJS_E_INVALID_ARG;
+  const uint32_t max_chunks = (w.stride + MTF_CHUNK - 1) / MTF_CHUNK;
+  hipLaunchKernelGGL(mtf_heads, dim3(nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b);
+  hipLaunchKernelGGL(mtf_chunk_lists, dim3(nb), dim3(1024), 0, s, w.stride, w.b);
+  hipLaunchKernelGGL(mtf_replay, dim3((max_chunks + 255) / 256, nb), dim3(256), 0, s, w.stride, w.b);
+  hipLaunchKernelGGL(mtf_emit, dim3(nb), dim3(1024), 0, s, w.stride, d_blen, w.b);
+  CJS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace cjs

@@ -1,0 +1,277 @@
+// pipeline.hip — per-GPU context (workspace + stream) and the bzip2 compress pipeline:
+//   RLE1/CRC/boundaries -> batched cyclic BWT -> MTF/RLE2 -> Huffman tables -> bit packing.
+// Mirrors the block loop of Bzip2.compressFile (J/Bzip2_joined_.js:2199-2249) for all blocks at once.
+#include "cjs_internal.h"
+#include "rle1.h"
+#include "mtf.h"
+#include "huff.h"
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+using namespace cjs;
+
+namespace cjs { int select_device(const cjs_opts* opts); }
+
+struct cjs_ctx {
+  int device = 0, level = 0;
+  uint32_t cap = 0;
+  size_t max_input = 0, max_blocks = 0;
+  hipStream_t stream = nullptr;
+  Arena arena;
+  Rle1Work rle;
+  BwtWork bwt;
+  MtfWork mtf;
+  HuffWork huff;
+  uint8_t* d_blocks = nullptr;
+  uint8_t* d_U = nullptr;
+  uint32_t* d_pidx = nullptr;
+  uint64_t* h_scalars = nullptr;   // pinned
+  EventTimer timer;
+};
+
+extern "C" int cjs_ctx_create(cjs_ctx** out, int device, size_t max_input, int level) {
+  if (!out) return CJS_E_INVALID_ARG;
+  *out = nullptr;
+  if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CJS_E_NO_DEVICE;
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return CJS_E_NO_DEVICE; }
+  if (device >= ndev) return CJS_E_INVALID_ARG;
+  CJS_HIP_TRY(hipSetDevice(device));
+  cjs_ctx* c = new (std::nothrow) cjs_ctx();
+  if (!c) return CJS_E_OUT_OF_MEMORY;
+  c->device = device; c->level = level; c->cap = (uint32_t)level * 100000u - 19u;
+  if (max_input == 0) max_input = 1;
+  c->max_input = max_input;
+  c->max_blocks = Rle1Work::max_blocks_for(max_input, c->cap);
+  const size_t elems = c->max_blocks * c->cap;
+  size_t bytes = Rle1Work::bytes_needed(max_input, c->cap) + BwtWork::bytes_needed(elems) +
+                 MtfWork::bytes_needed(c->max_blocks, c->cap) + HuffWork::bytes_needed(c->max_blocks, c->cap) +
+                 2 * (elems + 512) + 4 * c->max_blocks + 65536;
+  int rc = c->arena.init(bytes);
+  if (!rc) rc = c->rle.carve(c->arena, max_input, c->cap);
+  if (!rc) rc = c->bwt.carve(c->arena, elems);
+  if (!rc) rc = c->mtf.carve(c->arena, c->max_blocks, c->cap);
+  if (!rc) rc = c->huff.carve(c->arena, c->max_blocks, c->cap);
+  if (!rc) {
+    c->d_blocks = c->arena.take<uint8_t>(elems);
+    c->d_U = c->arena.take<uint8_t>(elems);
+    c->d_pidx = c->arena.take<uint32_t>(c->max_blocks);
+    if (!c->d_pidx) rc = CJS_E_OUT_OF_MEMORY;
+  }
+  if (!rc && hipStreamCreate(&c->stream) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipHostMalloc((void**)&c->h_scalars, 256) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) rc = c->timer.init(c->stream);
+  if (rc) { cjs_ctx_destroy(c); return rc; }
+  *out = c;
+  return 0;
+}
+
+extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  c->timer.destroy();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+  if (c->bwt.h_counters) (void)hipHostFree(c->bwt.h_counters);
+  c->arena.destroy();
+  delete c;
+}
+
+// Shared body: stage 0..tables for the whole stream, then pack blocks [first, first+count).
+static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, long first, long count, bool framed,
+                         uint8_t* d_out, size_t out_cap, uint64_t* out_bits, uint32_t* block_crcs, long crc_cap,
+                         long* total_blocks, cjs_stats* st) {
+  if (!c || level != c->level) return CJS_E_INVALID_ARG;
+  if (n > c->max_input) return CJS_E_INVALID_ARG;
+  if (((uintptr_t)d_out & 3) != 0) return CJS_E_INVALID_ARG;
+  CJS_HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (st) { memset(st, 0, sizeof *st); CJS_HIP_TRY(hipEventCreate(&ev0)); CJS_HIP_TRY(hipEventCreate(&ev1)); (void)hipEventRecord(ev0, s); }
+  uint32_t nb = 0;
+  if (st) c->timer.start();
+  CJS_TRY(rle1_run(s, c->rle, d_in, n, c->d_blocks, &nb));
+  uint32_t n_last = 0;
+  if (nb) {
+    CJS_HIP_TRY(hipMemcpyAsync(c->h_scalars, c->rle.block_len + (nb - 1), 4, hipMemcpyDeviceToHost, s));
+    CJS_HIP_TRY(hipStreamSynchronize(s));
+    n_last = ((uint32_t*)c->h_scalars)[0];
+  }
+  if (st) st->ms_rle1 = c->timer.stop();
+  if (total_blocks) *total_blocks = (long)nb;
+  if (first < 0 || first > (long)nb) return CJS_E_INVALID_ARG;
+  if (count < 0 || first + count > (long)nb) count = (long)nb - first;
+  // Everything up to the tables is computed only for the requested range of blocks.
+  const uint32_t f = (uint32_t)first, cnt = (uint32_t)count;
+  if (cnt) {
+    const bool has_last = f + cnt == nb;
+    const uint32_t rl_last = has_last ? n_last : c->cap;
+    if (st) c->timer.start();
+    CJS_TRY(bwt_run(s, c->bwt, c->d_blocks + (size_t)f * c->cap, cnt, c->cap, rl_last, true, c->d_U + (size_t)f * c->cap, c->d_pidx + f, st));
+    if (st) { st->ms_bwt = c->timer.stop(); c->timer.start(); }
+    // the MTF / Huffman stages index blocks absolutely; run them on the sub-range through offset views
+    MtfWork mv = c->mtf;
+    mv.b.hpos += (size_t)f * c->cap; mv.b.hsym += (size_t)f * c->cap; mv.b.hrank += (size_t)f * c->cap;
+    mv.b.lists += (size_t)f * mv.b.list_stride; mv.b.A += (size_t)f * mv.b.a_stride; mv.b.freq += (size_t)f * 258;
+    mv.b.alist += (size_t)f * 256; mv.b.asz += f; mv.b.nheads += f; mv.b.npos += f;
+    CJS_TRY(mtf_run(s, mv, c->d_U + (size_t)f * c->cap, cnt, c->rle.block_len + f));
+    if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_mtf = c->timer.stop(); c->timer.start(); }
+    HuffWork hv = c->huff;
+    hv.b.sel += (size_t)f * hv.b.sel_stride; hv.b.selj += (size_t)f * hv.b.sel_stride; hv.b.bcost += (size_t)f * hv.b.sel_stride;
+    hv.b.lens += (size_t)f * 6 * 258; hv.b.codes += (size_t)f * 6 * 258; hv.b.ngroups += f; hv.b.bitlen += f;
+    CJS_TRY(huff_tables_run(s, hv, cnt, mv.b.A, mv.b.a_stride, mv.b.npos, mv.b.asz, mv.b.freq, mv.b.alist));
+    if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_huff = c->timer.stop(); }
+  }
+  if (st) c->timer.start();
+  // output size check before any packing: sum of block bit lengths
+  CJS_HIP_TRY(hipMemsetAsync(d_out, 0, out_cap & ~(size_t)3, s));
+  const uint64_t start_bit = framed ? 32 : 0;
+  // (offsets kernel runs inside huff_pack_run; do a dry pass first to learn the size)
+  {
+    uint64_t need_bits = start_bit + (framed ? 80 : 0);
+    if (cnt) {
+      // bitlen[] of the range -> host (small)
+      uint32_t* hbl = (uint32_t*)malloc(sizeof(uint32_t) * cnt);
+      if (!hbl) return CJS_E_OUT_OF_MEMORY;
+      hipError_t e = hipMemcpyAsync(hbl, c->huff.b.bitlen + f, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) { free(hbl); return CJS_E_HIP; }
+      for (uint32_t k = 0; k < cnt; k++) need_bits += hbl[k];
+      free(hbl);
+    }
+    if ((need_bits + 7) / 8 + 8 > (out_cap & ~(size_t)3)) return CJS_E_OUTPUT_TOO_SMALL;
+  }
+  CJS_TRY(huff_pack_run(s, c->huff, nb, f, cnt, start_bit, level, framed ? 1 : 0, framed ? 1 : 0, c->mtf.b.A, c->mtf.b.a_stride,
+                        c->mtf.b.npos, c->mtf.b.asz, c->mtf.b.alist, c->rle.block_crc, c->d_pidx, (uint32_t*)d_out));
+  CJS_HIP_TRY(hipMemcpyAsync(c->h_scalars, c->huff.scalars, 8, hipMemcpyDeviceToHost, s));
+  if (block_crcs && nb) {
+    if ((long)nb > crc_cap) return CJS_E_OUTPUT_TOO_SMALL;
+    CJS_HIP_TRY(hipMemcpyAsync(block_crcs, c->rle.block_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s));
+  }
+  CJS_HIP_TRY(hipStreamSynchronize(s));
+  *out_bits = c->h_scalars[0];
+  if (st) {
+    st->ms_pack = c->timer.stop();
+    (void)hipEventRecord(ev1, s); (void)hipEventSynchronize(ev1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1);
+    st->ms_total = ms;
+    st->blocks = cnt; st->bytes_in = n; st->bytes_out = (*out_bits + 7) / 8;
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+  }
+  return 0;
+}
+
+extern "C" int cjs_bzip2_compress_device(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, uint8_t* d_out, size_t out_cap,
+                                         size_t* out_n, cjs_stats* stats) {
+  uint64_t bits = 0;
+  CJS_TRY(compress_core(c, d_in, n, level, 0, -1, true, d_out, out_cap, &bits, nullptr, 0, nullptr, stats));
+  *out_n = (size_t)((bits + 7) / 8);
+  return 0;
+}
+
+extern "C" int cjs_bzip2_compress_device_range(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, long first_block, long count,
+                                               uint8_t* d_out, size_t out_cap, uint64_t* out_bits, uint32_t* block_crcs, long crc_cap,
+                                               long* total_blocks, cjs_stats* stats) {
+  return compress_core(c, d_in, n, level, first_block, count, false, d_out, out_cap, out_bits, block_crcs, crc_cap, total_blocks, stats);
+}
+
+extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
+  if (!out || !out_n) return CJS_E_INVALID_ARG;
+  *out = nullptr; *out_n = 0;
+  if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;                 // J/Bzip2_joined_.js:2208
+  CJS_TRY(select_device(opts));
+  cjs_ctx* c = nullptr;
+  CJS_TRY(cjs_ctx_create(&c, -1, n, level));
+  const size_t out_cap = (n + n / 4 + 4096 + 3) & ~(size_t)3;
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  int rc = 0;
+  if (hipMalloc((void**)&d_in, n ? n : 4) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
+  if (!rc && hipMalloc((void**)&d_out, out_cap) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
+  if (!rc && n && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = CJS_E_HIP;
+  size_t len = 0;
+  cjs_stats* st = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->stats : nullptr;
+  if (!rc) rc = cjs_bzip2_compress_device(c, d_in, n, level, d_out, out_cap, &len, st);
+  uint8_t* host = nullptr;
+  if (!rc) { host = (uint8_t*)malloc(len ? len : 1); if (!host) rc = CJS_E_OUT_OF_MEMORY; }
+  if (!rc && hipMemcpy(host, d_out, len, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  cjs_ctx_destroy(c);
+  if (rc) { free(host); return rc; }
+  *out = host; *out_n = len;
+  return 0;
+}
+
+// ------------------------------------------------------------------ stage-level entry points (tests)
+extern "C" int cjs_stage_mtf(const uint8_t* U, const uint8_t* blocks, size_t n, int block_len, uint16_t* A, uint32_t* npos,
+                             uint32_t* freq, uint32_t* alphabet, const cjs_opts* opts) {
+  (void)blocks;   // the used-symbol set of a block equals that of its BWT (a permutation of it)
+  CJS_TRY(select_device(opts));
+  if (n == 0) return 0;
+  if (block_len <= 0) return CJS_E_INVALID_ARG;
+  const uint32_t stride = (uint32_t)block_len, nb = (uint32_t)((n + stride - 1) / stride);
+  Arena arena;
+  CJS_TRY(arena.init(MtfWork::bytes_needed(nb, stride) + (size_t)nb * stride + 4 * (size_t)nb + 65536));
+  MtfWork w;
+  int rc = w.carve(arena, nb, stride);
+  uint8_t* d_U = arena.take<uint8_t>((size_t)nb * stride);
+  uint32_t* d_len = arena.take<uint32_t>(nb);
+  if (!rc && (!d_U || !d_len)) rc = CJS_E_OUT_OF_MEMORY;
+  std::vector<uint32_t> lens(nb, stride);
+  lens[nb - 1] = (uint32_t)(n - (size_t)(nb - 1) * stride);
+  hipStream_t s = nullptr;
+  if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpy(d_U, U, n, hipMemcpyHostToDevice) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpy(d_len, lens.data(), 4 * (size_t)nb, hipMemcpyHostToDevice) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) rc = mtf_run(s, w, d_U, nb, d_len);
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) {
+    std::vector<uint32_t> hnpos(nb);
+    if (hipMemcpy(hnpos.data(), w.b.npos, 4 * (size_t)nb, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemcpy(freq, w.b.freq, 4 * 258 * (size_t)nb, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemcpy(alphabet, w.b.asz, 4 * (size_t)nb, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    for (uint32_t k = 0; k < nb && !rc; k++) {
+      npos[k] = hnpos[k];
+      if (hipMemcpy(A + (size_t)k * (stride + 1), w.b.A + (size_t)k * w.b.a_stride, 2 * (size_t)hnpos[k], hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    }
+  }
+  if (s) (void)hipStreamDestroy(s);
+  arena.destroy();
+  return rc;
+}
+
+extern "C" int cjs_stage_huff(const uint16_t* A, uint32_t npos, uint32_t alphabet, uint8_t* selectors, uint8_t* lengths,
+                              uint32_t* ngroups, const cjs_opts* opts) {
+  CJS_TRY(select_device(opts));
+  if (npos == 0 || alphabet == 0 || alphabet > 256) return CJS_E_INVALID_ARG;
+  const uint32_t stride = npos;    // any stride >= npos-1 works for the selector buffers
+  Arena arena;
+  CJS_TRY(arena.init(HuffWork::bytes_needed(1, stride) + 2 * (size_t)npos + 4096 * 4 + 65536));
+  HuffWork w;
+  int rc = w.carve(arena, 1, stride);
+  uint16_t* d_A = arena.take<uint16_t>(npos);
+  uint32_t* d_misc = arena.take<uint32_t>(2 + 258);
+  uint8_t* d_alist = arena.take<uint8_t>(256);
+  if (!rc && (!d_A || !d_misc || !d_alist)) rc = CJS_E_OUT_OF_MEMORY;
+  std::vector<uint32_t> misc(2 + 258, 0);
+  misc[0] = npos; misc[1] = alphabet;
+  for (uint32_t i = 0; i < npos; i++) { if (A[i] > alphabet + 1) { arena.destroy(); return CJS_E_INVALID_ARG; } misc[2 + A[i]]++; }
+  uint8_t al[256]; for (int i = 0; i < 256; i++) al[i] = (uint8_t)i;
+  hipStream_t s = nullptr;
+  if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpy(d_A, A, 2 * (size_t)npos, hipMemcpyHostToDevice) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpy(d_misc, misc.data(), 4 * misc.size(), hipMemcpyHostToDevice) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpy(d_alist, al, 256, hipMemcpyHostToDevice) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) rc = huff_tables_run(s, w, 1, d_A, npos, d_misc, d_misc + 1, d_misc + 2, d_alist);
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+  const uint32_t nsel = (npos + 49) / 50;
+  if (!rc && hipMemcpy(selectors, w.b.sel, nsel, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpy(lengths, w.b.lens, 6 * 258, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpy(ngroups, w.b.ngroups, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+  if (s) (void)hipStreamDestroy(s);
+  arena.destroy();
+  return rc;
+}

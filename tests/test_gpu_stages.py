@@ -101,3 +101,62 @@ def test_rle1_stage(hip, oracle, name):
                 bad = np.nonzero(gb != wb)[0]
                 raise AssertionError("level %d block %d: %d bytes differ, first at %d" % (level, k, bad.size, bad[0]))
             assert gcrc == wcrc, "level %d block %d crc %08x want %08x" % (level, k, gcrc, wcrc)
+
+
+MTF_INPUTS = ["banana", "aaaa", "mary", "zeros_5000", "ab_10000", "range256", "random_multi", "random4sym", "textgen_multi", "textgen_900k", "sample3", "sample1"]
+
+
+@pytest.mark.parametrize("name", MTF_INPUTS)
+def test_mtf_stage(hip, oracle, name):
+    data, block_len = BWT_INPUTS[name]
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    nb = -(-data.size // block_len)
+    U = np.concatenate([oracle.bwt_cyclic(data[k * block_len:(k + 1) * block_len])[0] for k in range(nb)])
+    rc, A, npos, freq, asz = hip.stage_mtf(U, data, block_len)
+    assert rc == 0
+    for k in range(nb):
+        blk = data[k * block_len:(k + 1) * block_len]
+        wa, wf, wasz = oracle.mtf_rle2(U[k * block_len:k * block_len + blk.size], blk)
+        assert asz[k] == wasz
+        assert npos[k] == wa.size, "block %d: npos %d want %d" % (k, npos[k], wa.size)
+        got = A[k, :wa.size]
+        if not np.array_equal(got, wa):
+            bad = np.nonzero(got != wa)[0]
+            raise AssertionError("block %d: %d symbols differ, first at %d (got %d want %d)" % (k, bad.size, bad[0], got[bad[0]], wa[bad[0]]))
+        assert np.array_equal(freq[k, :wasz + 2], wf)
+
+
+@pytest.mark.parametrize("name", MTF_INPUTS)
+def test_huff_stage(hip, oracle, name):
+    data, block_len = BWT_INPUTS[name]
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    blk = data[:block_len]
+    U, _ = oracle.bwt_cyclic(blk)
+    A, freq, asz = oracle.mtf_rle2(U, blk)
+    wng, wsel, wlens = oracle.huff_groups(A, asz)
+    rc, ng, sel, lens = hip.stage_huff(A, asz)
+    assert rc == 0
+    assert ng == wng
+    assert np.array_equal(lens, wlens), "code lengths differ"
+    assert np.array_equal(sel, wsel), "selectors differ at %s" % np.nonzero(sel != wsel)[0][:5]
+
+
+STREAMS = ["tiny_empty", "tiny_a", "tiny_banana", "sample0", "sample1", "sample3", "zeros_300000", "ab_10000", "range256_70000",
+           "random_250000", "random4sym_200000", "q2_run_at_block_end", "q2_count_fills_block", "q2_run_crosses_block",
+           "exact_block_99981", "exact_2blocks_199962", "long_runs_mixed", "run4_at_eof", "textgen_1000000_s1", "textgen_65536_s1"]
+
+
+def _golden_cases():
+    import support
+    g = support.load_golden("golden_small.json")
+    return [c for c in g["cases"] if c["algo"] == "Bzip2"]
+
+
+@pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: "%s-%d" % (c["name"], c["level"]))
+def test_bzip2_compress_golden(hip, case):
+    import support
+    data = recipes.build(case["recipe"])
+    rc, out = hip.bzip2_compress(data, case["level"])
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == case["out_len"], "length %d want %d" % (out.size, case["out_len"])
+    assert support.sha256(out) == case["out_sha256"]
