@@ -32,11 +32,16 @@ tools/textgen: tools/textgen.c
 	$(CC) -O2 -std=c99 -Wall -DTEXTGEN_MAIN -o $@ tools/textgen.c
 
 # N-API addon: thin shim over the C ABI (dlopen()s libcjs_hip.so next to it at load time)
+ifneq ($(wildcard $(PKG)/js/cjs_napi.cc),)
 napi: $(PKG)/js/cjs_napi.node
 $(PKG)/js/cjs_napi.node: $(PKG)/js/cjs_napi.cc include/cjs_hip.h
 	@if [ -f $(NODE_INC)/node_api.h ]; then \
 	  $(CXX) -O2 -std=c++17 -fPIC -shared -I$(NODE_INC) -Iinclude -o $@ $(PKG)/js/cjs_napi.cc -ldl ; \
 	else echo "node_api.h not found: skipping N-API addon"; fi
+else
+napi:
+	@echo "N-API addon source not present yet"
+endif
 
 clean:
 	rm -f $(CSRC)/*.o $(PKG)/libcjs_hip.so oracle/libcjs_oracle.so tools/libcjs_textgen.so tools/textgen $(PKG)/js/cjs_napi.node

@@ -102,7 +102,9 @@ extern "C" int cjs_stage_rle1(const uint8_t* in, size_t n, int level, uint8_t* b
   if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
   uint32_t nb = 0;
-  if (!rc) rc = rle1_run(s, w, d_in, n, d_blocks, &nb);
+  if (!rc) rc = rle1_run(s, w, d_in, n, &nb);
+  if (!rc) rc = rle1_finish(s, w, d_in, n, 0, nb, d_blocks);
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && ((long)nb > cap_blocks || (size_t)nb * cap > blocks_cap)) rc = CJS_E_OUTPUT_TOO_SMALL;
   if (!rc && nb) {
     std::vector<RleBlock> hb(nb);
@@ -114,6 +116,7 @@ extern "C" int cjs_stage_rle1(const uint8_t* in, size_t n, int level, uint8_t* b
   }
   *nblocks = (long)nb;
   if (s) (void)hipStreamDestroy(s);
+  w.release();
   arena.destroy();
   return rc;
 }

@@ -277,9 +277,10 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
 __global__ void huff_offsets(HuffBufs hb, const uint32_t* __restrict__ block_crc, uint32_t nb, uint32_t first, uint32_t count,
                              uint64_t start_bit, uint32_t* __restrict__ stream_crc_out) {
   if (threadIdx.x || blockIdx.x) return;
-  uint64_t bit = start_bit;
-  for (uint32_t k = first; k < first + count; k++) { hb.bitoff[k] = bit; bit += hb.bitlen[k]; }
-  hb.bitoff[first + count] = bit;
+  (void)first;
+  uint64_t bit = start_bit;                         // per-block buffers are indexed relative to `first`
+  for (uint32_t k = 0; k < count; k++) { hb.bitoff[k] = bit; bit += hb.bitlen[k]; }
+  hb.bitoff[count] = bit;
   uint32_t c = 0;
   for (uint32_t k = 0; k < nb; k++) c = ((c << 1) | (c >> 31)) ^ block_crc[k];      // Bzip2:2237
   *stream_crc_out = c;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(1024) void pack_block(HuffBufs hb, uint32_t first, 
   __shared__ uint32_t used16[17];
   __shared__ uint32_t ctab[6 * MAXSYM];
   __shared__ uint8_t ltab[6 * MAXSYM + 4];
-  const uint32_t blk = first + blockIdx.x;
+  const uint32_t blk = blockIdx.x;                  // relative to `first`; block_crc is absolute
   const uint32_t npos = npos_all[blk], asz = asz_all[blk], ng = hb.ngroups[blk];
   const uint32_t n = asz + 2, nsel = (npos + GSZ - 1) / GSZ;
   const uint16_t* A = Aall + (size_t)blk * a_stride;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(1024) void pack_block(HuffBufs hb, uint32_t first, 
   }
   __syncthreads();
   uint64_t bit = hb.bitoff[blk];
-  const uint32_t crc = block_crc[blk], pidx = pidx_all[blk];
+  const uint32_t crc = block_crc[first + blk], pidx = pidx_all[blk];
   // header: magic(48) crc(32) rand(1)+pidx(24) coarse(16) fine(16 each) ngroups(3)+nsel(15)
   const uint32_t coarse = used16[0];
   pack_phase(22, [&](uint32_t i) -> Item {
@@ -454,7 +455,7 @@ int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first,
   uint32_t* stream_crc = (uint32_t*)(w.scalars + 1);
   hipLaunchKernelGGL(huff_offsets, dim3(1), dim3(1), 0, s, w.b, d_block_crc, nb_total, first, count, start_bit, stream_crc);
   if (count) hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32);
-  hipLaunchKernelGGL(pack_frame, dim3(1), dim3(1), 0, s, w.b, first + count, level, write_header, write_trailer, stream_crc, d_out32, w.scalars);
+  hipLaunchKernelGGL(pack_frame, dim3(1), dim3(1), 0, s, w.b, count, level, write_header, write_trailer, stream_crc, d_out32, w.scalars);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
 }

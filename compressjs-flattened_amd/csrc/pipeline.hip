@@ -17,7 +17,7 @@ namespace cjs { int select_device(const cjs_opts* opts); }
 struct cjs_ctx {
   int device = 0, level = 0;
   uint32_t cap = 0;
-  size_t max_input = 0, max_blocks = 0;
+  size_t max_input = 0, max_blocks = 0, range_blocks = 0;
   hipStream_t stream = nullptr;
   Arena arena;
   Rle1Work rle;
@@ -32,6 +32,10 @@ struct cjs_ctx {
 };
 
 extern "C" int cjs_ctx_create(cjs_ctx** out, int device, size_t max_input, int level) {
+  return cjs_ctx_create_sharded(out, device, max_input, 0, level);
+}
+
+extern "C" int cjs_ctx_create_sharded(cjs_ctx** out, int device, size_t max_input, long max_range_blocks, int level) {
   if (!out) return CJS_E_INVALID_ARG;
   *out = nullptr;
   if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;
@@ -46,19 +50,21 @@ extern "C" int cjs_ctx_create(cjs_ctx** out, int device, size_t max_input, int l
   if (max_input == 0) max_input = 1;
   c->max_input = max_input;
   c->max_blocks = Rle1Work::max_blocks_for(max_input, c->cap);
-  const size_t elems = c->max_blocks * c->cap;
-  size_t bytes = Rle1Work::bytes_needed(max_input, c->cap) + BwtWork::bytes_needed(elems) +
-                 MtfWork::bytes_needed(c->max_blocks, c->cap) + HuffWork::bytes_needed(c->max_blocks, c->cap) +
-                 2 * (elems + 512) + 4 * c->max_blocks + 65536;
+  c->range_blocks = (max_range_blocks > 0 && (size_t)max_range_blocks < c->max_blocks) ? (size_t)max_range_blocks : c->max_blocks;
+  const size_t rb = c->range_blocks;
+  const size_t elems = rb * c->cap;
+  size_t bytes = Rle1Work::bytes_needed(max_input, c->cap, rb) + BwtWork::bytes_needed(elems) +
+                 MtfWork::bytes_needed(rb, c->cap) + HuffWork::bytes_needed(rb, c->cap) +
+                 2 * (elems + 512) + 4 * rb + 65536;
   int rc = c->arena.init(bytes);
-  if (!rc) rc = c->rle.carve(c->arena, max_input, c->cap);
+  if (!rc) rc = c->rle.carve(c->arena, max_input, c->cap, rb);
   if (!rc) rc = c->bwt.carve(c->arena, elems);
-  if (!rc) rc = c->mtf.carve(c->arena, c->max_blocks, c->cap);
-  if (!rc) rc = c->huff.carve(c->arena, c->max_blocks, c->cap);
+  if (!rc) rc = c->mtf.carve(c->arena, rb, c->cap);
+  if (!rc) rc = c->huff.carve(c->arena, rb, c->cap);
   if (!rc) {
     c->d_blocks = c->arena.take<uint8_t>(elems);
     c->d_U = c->arena.take<uint8_t>(elems);
-    c->d_pidx = c->arena.take<uint32_t>(c->max_blocks);
+    c->d_pidx = c->arena.take<uint32_t>(rb);
     if (!c->d_pidx) rc = CJS_E_OUT_OF_MEMORY;
   }
   if (!rc && hipStreamCreate(&c->stream) != hipSuccess) rc = CJS_E_HIP;
@@ -76,6 +82,7 @@ extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->bwt.h_counters) (void)hipHostFree(c->bwt.h_counters);
+  c->rle.release();
   c->arena.destroy();
   delete c;
 }
@@ -93,50 +100,39 @@ static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, l
   if (st) { memset(st, 0, sizeof *st); CJS_HIP_TRY(hipEventCreate(&ev0)); CJS_HIP_TRY(hipEventCreate(&ev1)); (void)hipEventRecord(ev0, s); }
   uint32_t nb = 0;
   if (st) c->timer.start();
-  CJS_TRY(rle1_run(s, c->rle, d_in, n, c->d_blocks, &nb));
-  uint32_t n_last = 0;
-  if (nb) {
+  CJS_TRY(rle1_run(s, c->rle, d_in, n, &nb));
+  if (total_blocks) *total_blocks = (long)nb;
+  if (first < 0 || first > (long)nb) return CJS_E_INVALID_ARG;
+  if (count < 0 || first + count > (long)nb) count = (long)nb - first;
+  const uint32_t f = (uint32_t)first, cnt = (uint32_t)count;
+  if (cnt > c->range_blocks) return CJS_E_INVALID_ARG;
+  uint32_t n_last = c->cap;
+  if (cnt && f + cnt == nb) {
     CJS_HIP_TRY(hipMemcpyAsync(c->h_scalars, c->rle.block_len + (nb - 1), 4, hipMemcpyDeviceToHost, s));
     CJS_HIP_TRY(hipStreamSynchronize(s));
     n_last = ((uint32_t*)c->h_scalars)[0];
   }
-  if (st) st->ms_rle1 = c->timer.stop();
-  if (total_blocks) *total_blocks = (long)nb;
-  if (first < 0 || first > (long)nb) return CJS_E_INVALID_ARG;
-  if (count < 0 || first + count > (long)nb) count = (long)nb - first;
-  // Everything up to the tables is computed only for the requested range of blocks.
-  const uint32_t f = (uint32_t)first, cnt = (uint32_t)count;
+  // all per-block buffers below are indexed relative to `first`; only rle.block_len / block_crc are absolute
+  CJS_TRY(rle1_finish(s, c->rle, d_in, n, f, cnt, c->d_blocks));
+  if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_rle1 = c->timer.stop(); }
   if (cnt) {
-    const bool has_last = f + cnt == nb;
-    const uint32_t rl_last = has_last ? n_last : c->cap;
     if (st) c->timer.start();
-    CJS_TRY(bwt_run(s, c->bwt, c->d_blocks + (size_t)f * c->cap, cnt, c->cap, rl_last, true, c->d_U + (size_t)f * c->cap, c->d_pidx + f, st));
+    CJS_TRY(bwt_run(s, c->bwt, c->d_blocks, cnt, c->cap, n_last, true, c->d_U, c->d_pidx, st));
     if (st) { st->ms_bwt = c->timer.stop(); c->timer.start(); }
-    // the MTF / Huffman stages index blocks absolutely; run them on the sub-range through offset views
-    MtfWork mv = c->mtf;
-    mv.b.hpos += (size_t)f * c->cap; mv.b.hsym += (size_t)f * c->cap; mv.b.hrank += (size_t)f * c->cap;
-    mv.b.lists += (size_t)f * mv.b.list_stride; mv.b.A += (size_t)f * mv.b.a_stride; mv.b.freq += (size_t)f * 258;
-    mv.b.alist += (size_t)f * 256; mv.b.asz += f; mv.b.nheads += f; mv.b.npos += f;
-    CJS_TRY(mtf_run(s, mv, c->d_U + (size_t)f * c->cap, cnt, c->rle.block_len + f));
+    CJS_TRY(mtf_run(s, c->mtf, c->d_U, cnt, c->rle.block_len + f));
     if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_mtf = c->timer.stop(); c->timer.start(); }
-    HuffWork hv = c->huff;
-    hv.b.sel += (size_t)f * hv.b.sel_stride; hv.b.selj += (size_t)f * hv.b.sel_stride; hv.b.bcost += (size_t)f * hv.b.sel_stride;
-    hv.b.lens += (size_t)f * 6 * 258; hv.b.codes += (size_t)f * 6 * 258; hv.b.ngroups += f; hv.b.bitlen += f;
-    CJS_TRY(huff_tables_run(s, hv, cnt, mv.b.A, mv.b.a_stride, mv.b.npos, mv.b.asz, mv.b.freq, mv.b.alist));
+    CJS_TRY(huff_tables_run(s, c->huff, cnt, c->mtf.b.A, c->mtf.b.a_stride, c->mtf.b.npos, c->mtf.b.asz, c->mtf.b.freq, c->mtf.b.alist));
     if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_huff = c->timer.stop(); }
   }
   if (st) c->timer.start();
-  // output size check before any packing: sum of block bit lengths
   CJS_HIP_TRY(hipMemsetAsync(d_out, 0, out_cap & ~(size_t)3, s));
   const uint64_t start_bit = framed ? 32 : 0;
-  // (offsets kernel runs inside huff_pack_run; do a dry pass first to learn the size)
-  {
+  {  // output size check before any packing: sum of the block bit lengths (small D2H)
     uint64_t need_bits = start_bit + (framed ? 80 : 0);
     if (cnt) {
-      // bitlen[] of the range -> host (small)
       uint32_t* hbl = (uint32_t*)malloc(sizeof(uint32_t) * cnt);
       if (!hbl) return CJS_E_OUT_OF_MEMORY;
-      hipError_t e = hipMemcpyAsync(hbl, c->huff.b.bitlen + f, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, s);
+      hipError_t e = hipMemcpyAsync(hbl, c->huff.b.bitlen, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipStreamSynchronize(s);
       if (e != hipSuccess) { free(hbl); return CJS_E_HIP; }
       for (uint32_t k = 0; k < cnt; k++) need_bits += hbl[k];

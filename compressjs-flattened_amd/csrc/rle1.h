@@ -14,16 +14,20 @@ struct RleBlock {
 
 struct Rle1Work {
   size_t max_in = 0;
-  uint32_t cap = 0, max_blocks = 0, max_segs = 0;
+  uint32_t cap = 0, max_blocks = 0, max_segs = 0, range_blocks = 0;
+  uint32_t* h_n = nullptr;       // pinned host scalar
   uint64_t *fb = nullptr, *lb = nullptr, *gt = nullptr;
   RleBlock* blocks = nullptr;
   uint32_t *block_len = nullptr, *block_crc = nullptr, *nblocks = nullptr, *seg_crc = nullptr;
   static size_t max_blocks_for(size_t max_in, uint32_t cap) { return max_in / ((size_t)cap * 4 / 5) + 2; }
   static size_t max_segs_for(uint32_t cap) { return ((size_t)cap * 51 + 16383) / 16384 + 1; }
-  static size_t bytes_needed(size_t max_in, uint32_t cap);
-  int carve(Arena& a, size_t max_in, uint32_t cap);
+  // range_blocks = max number of blocks materialised / CRC'd per call (0 = all blocks of the stream)
+  static size_t bytes_needed(size_t max_in, uint32_t cap, size_t range_blocks = 0);
+  int carve(Arena& a, size_t max_in, uint32_t cap, size_t range_blocks = 0);
+  void release() { if (h_n) (void)hipHostFree(h_n); h_n = nullptr; }
 };
 
-int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint8_t* d_blocks, uint32_t* nblocks_host);
+int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host);
+int rle1_finish(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t first, uint32_t count, uint8_t* d_blocks);
 
 }  // namespace cjs

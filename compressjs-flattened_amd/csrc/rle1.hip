@@ -275,12 +275,13 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
 __global__ __launch_bounds__(256) void rle_materialize(const uint8_t* __restrict__ in, uint64_t N, uint32_t cap,
                                                        const uint64_t* __restrict__ run_start_in, const uint64_t* __restrict__ next_bnd,
                                                        const uint64_t* __restrict__ gt, const RleBlock* __restrict__ blocks,
-                                                       const uint32_t* __restrict__ nblocks_p, uint8_t* __restrict__ out) {
+                                                       const uint32_t* __restrict__ nblocks_p, uint32_t first, uint32_t count,
+                                                       uint8_t* __restrict__ out) {
   __shared__ uint32_t smem[256 + 16];
   __shared__ uint32_t nb_first[256];
-  const uint32_t nblocks = *nblocks_p;
+  const uint32_t nblocks = *nblocks_p < first + count ? *nblocks_p : first + count;   // blocks [first, nblocks)
   const uint64_t tile_start = (uint64_t)blockIdx.x * RT;
-  if (nblocks == 0 || tile_start >= blocks[nblocks - 1].e) return;
+  if (nblocks <= first || tile_start >= blocks[nblocks - 1].e || tile_start + RT <= blocks[first].s) return;
   uint8_t b[16]; uint32_t bm; uint64_t rs;
   run_starts<256, 16>(in, N, tile_start, run_start_in[blockIdx.x], smem, b, bm, rs);
   const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * 16;
@@ -317,13 +318,13 @@ __global__ __launch_bounds__(256) void rle_materialize(const uint8_t* __restrict
   const uint32_t sfx = rq ? nb_first[rq - 1] : 0u;        // max over later threads of (0x10000 - first)
   const uint64_t next_after_me = sfx ? tile_start + (0x10000u - sfx) : next_bnd[blockIdx.x];
   // blocks overlapping this tile: first block with e > tile_start
-  uint32_t lo = 0, hi = nblocks - 1;
+  uint32_t lo = first, hi = nblocks - 1;
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blocks[mid].e > tile_start) hi = mid; else lo = mid + 1; }
   const uint64_t tile_end = tile_start + RT;
   for (uint32_t k = lo; k < nblocks; k++) {
     const RleBlock bd = blocks[k];
     if (bd.s >= tile_end) break;
-    uint8_t* o = out + (size_t)k * cap;
+    uint8_t* o = out + (size_t)(k - first) * cap;
     uint32_t run = exc;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -375,10 +376,10 @@ constexpr uint32_t CRC_SEG = 16384;   // bytes per workgroup: 256 threads x 64 b
 
 __global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict__ in, const RleBlock* __restrict__ blocks,
                                                        const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
-                                                       uint32_t* __restrict__ seg_crc) {
+                                                       uint32_t first, uint32_t* __restrict__ seg_crc) {
   __shared__ uint32_t tab[256];
   __shared__ uint32_t part[256];
-  const uint32_t k = blockIdx.y;
+  const uint32_t k = first + blockIdx.y;
   if (k >= *nblocks_p) return;
   const RleBlock bd = blocks[k];
   const uint64_t seg_start = bd.s + (uint64_t)blockIdx.x * CRC_SEG;
@@ -407,13 +408,14 @@ __global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) seg_crc[(size_t)k * max_segs + blockIdx.x] = part[0];
+  if (threadIdx.x == 0) seg_crc[(size_t)blockIdx.y * max_segs + blockIdx.x] = part[0];
 }
 
 __global__ void rle_crc_final(const RleBlock* __restrict__ blocks, const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
-                              const uint32_t* __restrict__ seg_crc, uint32_t* __restrict__ block_crc, uint32_t* __restrict__ block_len) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= *nblocks_p) return;
+                              uint32_t first, uint32_t count, const uint32_t* __restrict__ seg_crc, uint32_t* __restrict__ block_crc) {
+  const uint32_t rel = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = first + rel;
+  if (rel >= count || k >= *nblocks_p) return;
   const RleBlock bd = blocks[k];
   const uint64_t n = bd.e - bd.s;
   uint32_t crc = 0;
@@ -421,16 +423,20 @@ __global__ void rle_crc_final(const RleBlock* __restrict__ blocks, const uint32_
   const uint32_t xfull = gf_xpow8(CRC_SEG);
   for (uint32_t sgi = 0; done < n; sgi++) {
     const uint64_t l = n - done < CRC_SEG ? n - done : CRC_SEG;
-    crc = gf_mul(crc, l == CRC_SEG ? xfull : gf_xpow8(l)) ^ seg_crc[(size_t)k * max_segs + sgi];
+    crc = gf_mul(crc, l == CRC_SEG ? xfull : gf_xpow8(l)) ^ seg_crc[(size_t)rel * max_segs + sgi];
     done += l;
   }
   crc ^= gf_mul(0xFFFFFFFFu, gf_xpow8(n));     // init = ~0 carried through n bytes
   block_crc[k] = ~crc;
-  block_len[k] = bd.len;
+}
+
+__global__ void rle_block_lens(const RleBlock* __restrict__ blocks, const uint32_t* __restrict__ nblocks_p, uint32_t* __restrict__ block_len) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < *nblocks_p) block_len[k] = blocks[k].len;
 }
 
 // ------------------------------------------------------------------------------------------
-size_t Rle1Work::bytes_needed(size_t max_in, uint32_t cap) {
+size_t Rle1Work::bytes_needed(size_t max_in, uint32_t cap, size_t range_blocks) {
   const size_t Tn = (max_in + RT - 1) / RT + 2;
   const size_t maxb = max_blocks_for(max_in, cap);
   const size_t segs = max_segs_for(cap);
@@ -438,10 +444,10 @@ size_t Rle1Work::bytes_needed(size_t max_in, uint32_t cap) {
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
   add(Tn * 8); add(Tn * 8); add((Tn + 1) * 8);
   add(maxb * sizeof(RleBlock)); add(maxb * 4); add(maxb * 4); add(64);
-  add(maxb * segs * 4);
+  add((range_blocks ? range_blocks : maxb) * segs * 4);
   return b + 4096;
 }
-int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_) {
+int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_, size_t range_blocks_) {
   max_in = max_in_; cap = cap_;
   const size_t Tn = (max_in + RT - 1) / RT + 2;
   max_blocks = (uint32_t)max_blocks_for(max_in, cap);
@@ -449,13 +455,14 @@ int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_) {
   fb = a.take<uint64_t>(Tn); lb = a.take<uint64_t>(Tn); gt = a.take<uint64_t>(Tn + 1);
   blocks = a.take<RleBlock>(max_blocks); block_len = a.take<uint32_t>(max_blocks); block_crc = a.take<uint32_t>(max_blocks);
   nblocks = a.take<uint32_t>(16);
-  seg_crc = a.take<uint32_t>((size_t)max_blocks * max_segs);
+  range_blocks = (uint32_t)(range_blocks_ ? range_blocks_ : max_blocks);
+  seg_crc = a.take<uint32_t>((size_t)range_blocks * max_segs);
   return seg_crc ? 0 : CJS_E_OUT_OF_MEMORY;
 }
 
-// Runs stage 0 for input d_in[0..N).  d_blocks receives the RLE1 bytes (stride = cap per block).
-// Leaves the number of blocks in w.nblocks[0] (device) and returns it in *nblocks_host (syncs the stream).
-int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint8_t* d_blocks, uint32_t* nblocks_host) {
+// Stage 0a: block boundaries of the whole stream d_in[0..N).  Leaves descriptors / lengths on the device,
+// returns the number of blocks in *nblocks_host (syncs the stream).
+int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host) {
   if (N > w.max_in) return CJS_E_INVALID_ARG;
   if (N == 0) { *nblocks_host = 0; CJS_HIP_TRY(hipMemsetAsync(w.nblocks, 0, 4, s)); return 0; }
   const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
@@ -464,17 +471,24 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint8_
   hipLaunchKernelGGL(rle_tile_count, dim3(Tn), dim3(256), 0, s, d_in, N, w.lb, w.gt);
   hipLaunchKernelGGL(rle_scan_counts, dim3(1), dim3(1024), 0, s, w.gt, Tn);
   hipLaunchKernelGGL(rle_walk, dim3(1), dim3(1024), 0, s, d_in, N, w.cap, Tn, w.lb, w.fb, w.gt, w.blocks, w.max_blocks, w.nblocks);
-  hipLaunchKernelGGL(rle_materialize, dim3(Tn), dim3(256), 0, s, d_in, N, w.cap, w.lb, w.fb, w.gt, w.blocks, w.nblocks, d_blocks);
-  hipLaunchKernelGGL(rle_crc_partial, dim3(w.max_segs, w.max_blocks), dim3(256), 0, s, d_in, w.blocks, w.nblocks, w.max_segs, w.seg_crc);
-  hipLaunchKernelGGL(rle_crc_final, dim3((w.max_blocks + 63) / 64), dim3(64), 0, s, w.blocks, w.nblocks, w.max_segs, w.seg_crc, w.block_crc, w.block_len);
+  hipLaunchKernelGGL(rle_block_lens, dim3((w.max_blocks + 255) / 256), dim3(256), 0, s, w.blocks, w.nblocks, w.block_len);
   CJS_HIP_TRY(hipGetLastError());
-  uint32_t* h = nullptr;
-  CJS_HIP_TRY(hipHostMalloc((void**)&h, 16));
-  hipError_t e1 = hipMemcpyAsync(h, w.nblocks, 4, hipMemcpyDeviceToHost, s);
-  hipError_t e2 = hipStreamSynchronize(s);
-  *nblocks_host = h[0];
-  (void)hipHostFree(h);
-  if (e1 != hipSuccess || e2 != hipSuccess) return CJS_E_HIP;
+  if (!w.h_n) CJS_HIP_TRY(hipHostMalloc((void**)&w.h_n, 16));
+  CJS_HIP_TRY(hipMemcpyAsync(w.h_n, w.nblocks, 4, hipMemcpyDeviceToHost, s));
+  CJS_HIP_TRY(hipStreamSynchronize(s));
+  *nblocks_host = w.h_n[0];
+  return 0;
+}
+
+// Stage 0b: RLE1 bytes (d_blocks, block k at (k-first)*cap) and CRCs (block_crc[k], absolute) of blocks [first, first+count)
+int rle1_finish(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t first, uint32_t count, uint8_t* d_blocks) {
+  if (N == 0 || count == 0) return 0;
+  if (count > w.range_blocks) return CJS_E_INVALID_ARG;
+  const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
+  hipLaunchKernelGGL(rle_materialize, dim3(Tn), dim3(256), 0, s, d_in, N, w.cap, w.lb, w.fb, w.gt, w.blocks, w.nblocks, first, count, d_blocks);
+  hipLaunchKernelGGL(rle_crc_partial, dim3(w.max_segs, count), dim3(256), 0, s, d_in, w.blocks, w.nblocks, w.max_segs, first, w.seg_crc);
+  hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, s, w.blocks, w.nblocks, w.max_segs, first, count, w.seg_crc, w.block_crc);
+  CJS_HIP_TRY(hipGetLastError());
   return 0;
 }
 

@@ -1,0 +1,42 @@
+'use strict';
+/* Bzip2.js — drop-in front for the reference's `Bzip2` object (J/Bzip2_joined_.js:2198-2253):
+ * same method names, argument meaning and error behaviour; the per-block pipeline runs in
+ * libcjs_hip.so on an MI355X through the N-API addon.  No JavaScript fallback. */
+var common = require('./common.js');
+
+var Err = { OK: 0, LAST_BLOCK: -1, NOT_BZIP_DATA: -2, UNEXPECTED_INPUT_EOF: -3, UNEXPECTED_OUTPUT_EOF: -4,
+            DATA_ERROR: -5, OUT_OF_MEMORY: -6, OBSOLETE_INPUT: -7, END_OF_BLOCK: -8 };
+var Messages = {};
+Messages[Err.NOT_BZIP_DATA] = 'Not bzip data';
+Messages[Err.DATA_ERROR] = 'Data error';
+Messages[Err.OUT_OF_MEMORY] = 'Out of memory';
+Messages[Err.OBSOLETE_INPUT] = 'Obsolete (pre 0.9.5) bzip format not supported.';
+
+function rethrow(e) {
+  if (e && typeof e.cjsCode === 'number') {
+    var code = e.cjsCode;
+    if (code === -20) { throw new Error('Invalid block size multiplier'); }      // J/Bzip2_joined_.js:2208
+    if (Messages[code]) { var t = new TypeError(Messages[code]); t.errorCode = code; throw t; }   // :1385-1391
+    var g = new Error(e.message); g.errorCode = code; throw g;
+  }
+  throw e;
+}
+
+var Bzip2 = Object.create(null);
+Bzip2.compressFile = function (inStream, outStream, props) {
+  var level = 9;
+  if (typeof props === 'number') { level = props; }
+  if (level < 1 || level > 9) { throw new Error('Invalid block size multiplier'); }
+  var input = common.coerceInput(inStream);
+  var result;
+  try { result = common.addon().bzip2Compress(input.bytes, level); } catch (e) { rethrow(e); }
+  return common.deliver(result, outStream);
+};
+Bzip2.decompressFile = function (inStream, outStream, multistream) {
+  var input = common.coerceInput(inStream);
+  var result;
+  try { result = common.addon().bzip2Decompress(input.bytes, multistream ? 1 : 0); } catch (e) { rethrow(e); }
+  return common.deliver(result, outStream);
+};
+Bzip2.Err = Err;
+module.exports = Bzip2;

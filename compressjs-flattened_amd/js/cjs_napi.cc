@@ -1,0 +1,135 @@
+// cjs_napi.cc — thin N-API shim over the C ABI of libcjs_hip.so (include/cjs_hip.h).
+// It does no compression work: it dlopen()s the HIP library that sits next to the package, hands it
+// the bytes of a Uint8Array/Buffer and wraps the malloc'd result as an external ArrayBuffer whose
+// finalizer calls cjs_free.  Coercion of streams/arrays and error -> exception mapping live in the JS
+// fronts (Bzip2.js / BWTC.js), exactly where the reference does them (Util.coerceInputStream etc.).
+#include <node_api.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include "cjs_hip.h"
+
+namespace {
+
+struct Api {
+  void* handle = nullptr;
+  int (*bzip2_compress)(const uint8_t*, size_t, int, uint8_t**, size_t*, const cjs_opts*) = nullptr;
+  int (*bzip2_decompress)(const uint8_t*, size_t, int, uint8_t**, size_t*, const cjs_opts*) = nullptr;
+  int (*bwtc_compress)(const uint8_t*, size_t, int, uint8_t**, size_t*, const cjs_opts*) = nullptr;
+  int (*bwtc_decompress)(const uint8_t*, size_t, uint8_t**, size_t*, const cjs_opts*) = nullptr;
+  void (*free_)(void*) = nullptr;
+  const char* (*strerror_)(int) = nullptr;
+  int (*device_count)(void) = nullptr;
+  const char* (*version)(void) = nullptr;
+  std::string error;
+} api;
+
+bool load_api() {
+  if (api.handle) return true;
+  Dl_info info;
+  std::string dir = ".";
+  if (dladdr((void*)&load_api, &info) && info.dli_fname) {
+    dir = info.dli_fname;
+    size_t p = dir.find_last_of('/');
+    dir = p == std::string::npos ? "." : dir.substr(0, p);
+  }
+  const char* env = getenv("CJS_HIP_LIB");
+  std::string path = env ? env : dir + "/../libcjs_hip.so";
+  api.handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!api.handle) { api.error = std::string("cannot load libcjs_hip.so: ") + dlerror(); return false; }
+#define SYM(field, name) *(void**)(&api.field) = dlsym(api.handle, name); if (!api.field) { api.error = "missing symbol " name; api.handle = nullptr; return false; }
+  SYM(bzip2_compress, "cjs_bzip2_compress") SYM(bzip2_decompress, "cjs_bzip2_decompress")
+  SYM(bwtc_compress, "cjs_bwtc_compress") SYM(bwtc_decompress, "cjs_bwtc_decompress")
+  SYM(free_, "cjs_free") SYM(strerror_, "cjs_strerror") SYM(device_count, "cjs_device_count") SYM(version, "cjs_version")
+#undef SYM
+  return true;
+}
+
+void finalize_buf(napi_env, void* data, void*) { if (api.free_) api.free_(data); }
+
+napi_value throw_code(napi_env env, int code) {
+  napi_value err, msg, num;
+  const char* text = api.strerror_ ? api.strerror_(code) : "cjs error";
+  napi_create_string_utf8(env, text, NAPI_AUTO_LENGTH, &msg);
+  napi_create_error(env, nullptr, msg, &err);
+  napi_create_int32(env, code, &num);
+  napi_set_named_property(env, err, "cjsCode", num);
+  napi_throw(env, err);
+  return nullptr;
+}
+
+bool get_bytes(napi_env env, napi_value v, const uint8_t** p, size_t* n) {
+  bool is_ta = false, is_buf = false;
+  napi_is_buffer(env, v, &is_buf);
+  if (is_buf) { void* d; napi_get_buffer_info(env, v, &d, n); *p = (const uint8_t*)d; return true; }
+  napi_is_typedarray(env, v, &is_ta);
+  if (is_ta) {
+    napi_typedarray_type t; size_t len; void* d; napi_value ab; size_t off;
+    napi_get_typedarray_info(env, v, &t, &len, &d, &ab, &off);
+    if (t != napi_uint8_array && t != napi_uint8_clamped_array && t != napi_int8_array) return false;
+    *p = (const uint8_t*)d; *n = len; return true;
+  }
+  return false;
+}
+
+napi_value wrap_result(napi_env env, uint8_t* data, size_t n) {
+  napi_value ab, ta;
+  if (napi_create_external_arraybuffer(env, data, n, finalize_buf, nullptr, &ab) != napi_ok) {
+    // some runtimes forbid external buffers: copy instead
+    void* dst;
+    napi_create_arraybuffer(env, n, &dst, &ab);
+    memcpy(dst, data, n);
+    api.free_(data);
+  }
+  napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta);
+  return ta;
+}
+
+template <int KIND>   // 0 bzip2 compress, 1 bzip2 decompress, 2 bwtc compress, 3 bwtc decompress
+napi_value call_stream(napi_env env, napi_callback_info info) {
+  if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
+  size_t argc = 2; napi_value argv[2];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* p = nullptr; size_t n = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &p, &n)) { napi_throw_type_error(env, nullptr, "expected a Uint8Array or Buffer"); return nullptr; }
+  int32_t arg = KIND == 1 ? 0 : 9;
+  if (argc >= 2) napi_get_value_int32(env, argv[1], &arg);
+  uint8_t* out = nullptr; size_t out_n = 0;
+  static const uint8_t dummy = 0;
+  if (!p) p = &dummy;
+  int rc;
+  if (KIND == 0) rc = api.bzip2_compress(p, n, arg, &out, &out_n, nullptr);
+  else if (KIND == 1) rc = api.bzip2_decompress(p, n, arg, &out, &out_n, nullptr);
+  else if (KIND == 2) rc = api.bwtc_compress(p, n, arg, &out, &out_n, nullptr);
+  else rc = api.bwtc_decompress(p, n, &out, &out_n, nullptr);
+  if (rc != 0) return throw_code(env, rc);
+  return wrap_result(env, out, out_n);
+}
+
+napi_value device_count(napi_env env, napi_callback_info) {
+  if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
+  napi_value v; napi_create_int32(env, api.device_count(), &v); return v;
+}
+napi_value version(napi_env env, napi_callback_info) {
+  if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
+  napi_value v; napi_create_string_utf8(env, api.version(), NAPI_AUTO_LENGTH, &v); return v;
+}
+
+napi_value init(napi_env env, napi_value exports) {
+  napi_property_descriptor props[] = {
+    {"bzip2Compress", nullptr, call_stream<0>, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"bzip2Decompress", nullptr, call_stream<1>, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"bwtcCompress", nullptr, call_stream<2>, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"bwtcDecompress", nullptr, call_stream<3>, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"deviceCount", nullptr, device_count, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"version", nullptr, version, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+  return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(cjs_napi, init)

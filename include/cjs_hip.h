@@ -75,6 +75,9 @@ const char *cjs_version(void);
  * A context owns the per-GPU workspace (sized for max_input bytes at `level`) and one stream. */
 typedef struct cjs_ctx cjs_ctx;
 int cjs_ctx_create(cjs_ctx **ctx, int device, size_t max_input, int level);
+/* as above, but the per-block workspace (suffix sorter, MTF, Huffman) is sized for at most
+ * max_range_blocks blocks per call: for cjs_bzip2_compress_device_range on a replicated stream */
+int cjs_ctx_create_sharded(cjs_ctx **ctx, int device, size_t max_input, long max_range_blocks, int level);
 void cjs_ctx_destroy(cjs_ctx *ctx);
 /* d_in/d_out are device pointers; d_out has out_cap bytes; *out_n receives the stream length.
  * Synchronous on return (the context stream has drained). */
