@@ -143,7 +143,8 @@ def main():
             g = json.load(open(gpath))["cases"][0]
             verify["golden"] = gname
             verify["bit_exact_vs_reference_js"] = bool(g["out_len"] == out_n and g["out_sha256"] == verify["out_sha256"])
-            assert verify["bit_exact_vs_reference_js"], "output differs from the reference JS golden (%s)" % gname
+            if not args.no_verify:
+                assert verify["bit_exact_vs_reference_js"], "output differs from the reference JS golden (%s)" % gname
         out_bytes_total = int(out_n)
     else:
         bits, crcs = res

@@ -15,16 +15,28 @@
 // Integer sort/scan only (no MFMA); HBM-bound on the radix scatter passes.
 #include "cjs_internal.h"
 #include "prims.hpp"
+#include <stdlib.h>
 
 namespace cjs {
 
 struct Geom { uint32_t nb, stride, n_last; };
 __device__ __forceinline__ uint32_t blk_len(const Geom& g, uint32_t blk) { return blk == g.nb - 1 ? g.n_last : g.stride; }
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2),
+// so workgroup w = 8*j + x works on tile x*ceil(T/8) + j: every XCD walks ONE contiguous range of the
+// suffix array, i.e. one block at a time, and that block's rank array (3.6 MB) stays in its L2 while the
+// kernel scatters / gathers ranks at random positions of it.  Speed only; any mapping is correct.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t wg, uint32_t T) {
+  const uint32_t per = (T + 7u) >> 3;
+  return (wg & 7u) * per + (wg >> 3);
+}
+__host__ __device__ __forceinline__ uint32_t xcd_grid(uint32_t T) { return ((T + 7u) >> 3) << 3; }
+
 // ------------------------------------------------------------------------------------------
 // LSD radix sort pass: histogram -> per-bin scan over tiles -> stable scatter
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+template <typename K>
+__global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, uint32_t n, int shift,
                                                uint32_t* __restrict__ hist, uint32_t T) {
   __shared__ uint32_t h[4][256];
   const int tid = threadIdx.x, w = tid >> 6;
@@ -67,10 +79,11 @@ __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
   return peers;
 }
 
-__global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                  uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
+template <typename K>
+__global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                  K* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
                                                   const uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ bintot) {
-  __shared__ uint64_t skey[RS_TILE];
+  __shared__ K skey[RS_TILE];
   __shared__ uint32_t sval[RS_TILE];
   __shared__ uint32_t wcnt[4][256];
   __shared__ uint32_t goff[256];
@@ -80,14 +93,14 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
   const uint64_t base = (uint64_t)tile * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)n - base < RS_TILE ? (uint64_t)n - base : RS_TILE);
   for (int i = tid; i < 1024; i += 256) (&wcnt[0][0])[i] = 0;
-  uint64_t k[16];
+  K k[16];
   uint32_t v[16];
   uint32_t rk[16];
 #pragma unroll
   for (int s = 0; s < 16; s++) {
     const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
     const bool ok = loc < nvalid;
-    k[s] = ok ? kin[base + loc] : ~0ull;
+    k[s] = ok ? kin[base + loc] : (K)~(K)0;
     v[s] = ok ? vin[base + loc] : 0u;
   }
   __syncthreads();
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
   for (int it = 0; it < 16; it++) {
     const uint32_t j = (uint32_t)it * 256u + tid;
     if (j < nvalid) {
-      const uint64_t kk = skey[j];
+      const K kk = skey[j];
       const uint32_t dst = goff[(uint32_t)(kk >> shift) & 255u] + j;
       kout[dst] = kk;
       vout[dst] = sval[j];
@@ -137,21 +150,20 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
 // ------------------------------------------------------------------------------------------
 // suffix-sort kernels
 // ------------------------------------------------------------------------------------------
-// round 0 keys: (block id, first 4 symbols).  cyclic: bytes wrap; sentinel: 9-bit symbols, 0 = past the end
-__global__ __launch_bounds__(256) void bwt_init_keys(const uint8_t* __restrict__ T, Geom g, int cyclic, uint32_t M,
+// round 0 keys: (block id, first nsym symbols).  cyclic: bytes wrap; sentinel: 9-bit symbols, 0 = past the end
+__global__ __launch_bounds__(256) void bwt_init_keys(const uint8_t* __restrict__ T, Geom g, int cyclic, int nsym, uint32_t M,
                                                      uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ pos) {
   for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < M; a += (uint64_t)gridDim.x * 256) {
     const uint32_t blk = (uint32_t)(a / g.stride), i = (uint32_t)(a - (uint64_t)blk * g.stride), n = blk_len(g, blk);
     const uint8_t* t = T + (size_t)blk * g.stride;
     uint64_t k = 0;
     if (cyclic) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) { uint32_t x = i + j; while (x >= n) x -= n; k = (k << 8) | t[x]; }
-      k |= (uint64_t)blk << 32;
+      uint32_t x = i;
+      for (int j = 0; j < nsym; j++) { k = (k << 8) | t[x]; if (++x == n) x = 0; }
+      k |= (uint64_t)blk << (8 * nsym);
     } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++) { uint32_t x = i + j; k = (k << 9) | (x < n ? (uint32_t)t[x] + 1u : 0u); }
-      k |= (uint64_t)blk << 36;
+      for (int j = 0; j < nsym; j++) { const uint32_t x = i + j; k = (k << 9) | (x < n ? (uint32_t)t[x] + 1u : 0u); }
+      k |= (uint64_t)blk << (9 * nsym);
     }
     key[a] = k; val[a] = i; pos[a] = (uint32_t)a;
   }
@@ -160,14 +172,21 @@ __global__ __launch_bounds__(256) void bwt_init_keys(const uint8_t* __restrict__
 // round r>=1 keys: (group ordinal, rank of suffix i+h)
 __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint32_t A, uint32_t h, const uint32_t* __restrict__ R,
                                                        const uint32_t* __restrict__ val, const uint32_t* __restrict__ pos,
-                                                       const uint32_t* __restrict__ gord, uint64_t* __restrict__ key) {
-  for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < A; a += (uint64_t)gridDim.x * 256) {
-    const uint32_t blk = pos[a] / g.stride, n = blk_len(g, blk);
-    uint64_t j = (uint64_t)val[a] + h;
-    uint32_t kk;
-    if (cyclic) { j %= n; kk = R[(size_t)blk * g.stride + j] + 1u; }
-    else kk = j < n ? R[(size_t)blk * g.stride + j] + 1u : 0u;
-    key[a] = ((uint64_t)gord[a] << 20) | kk;
+                                                       const uint32_t* __restrict__ gord, uint64_t* __restrict__ key, uint32_t T) {
+  const uint32_t tile = xcd_tile(blockIdx.x, T);
+  if (tile >= T) return;
+  const uint64_t base = (uint64_t)tile * RS_TILE;
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint64_t a = base + (uint32_t)it * 256 + threadIdx.x;
+    if (a < A) {
+      const uint32_t blk = pos[a] / g.stride, n = blk_len(g, blk);
+      uint64_t j = (uint64_t)val[a] + h;
+      uint32_t kk;
+      if (cyclic) { if (j >= n) j %= n; kk = R[(size_t)blk * g.stride + j] + 1u; }
+      else kk = j < n ? R[(size_t)blk * g.stride + j] + 1u : 0u;
+      key[a] = ((uint64_t)gord[a] << 20) | kk;
+    }
   }
 }
 
@@ -226,59 +245,79 @@ __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ ti
   if (threadIdx.x == 0) { counters[0] = c0; counters[1] = c1; }
 }
 
-// regroup: new ranks -> R, singletons -> SA, survivors compacted into the next active arrays
+// regroup: new ranks -> R (scattered 4-byte stores), singletons -> SA, survivors compacted into the next
+// active arrays.  Fully lane-striped: the per-element prefix quantities come from 4096-bit masks
+// (wave ballots) + a 64-word scan, so every global access of a wave touches consecutive addresses.
 __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                  const uint32_t* __restrict__ pos, uint32_t A, Geom g,
                                                  const uint32_t* __restrict__ tile_cnt, uint32_t T,
                                                  uint32_t* __restrict__ R, uint32_t* __restrict__ SA,
                                                  uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord) {
-  __shared__ uint32_t sm[4];
-  __shared__ uint32_t mx[256];
-  const uint32_t tile = blockIdx.x;
-  const uint64_t a0 = (uint64_t)tile * RS_TILE + (uint32_t)threadIdx.x * 16u;
-  uint64_t k[18];
-#pragma unroll
-  for (int i = 0; i < 18; i++) {
-    const uint64_t a = a0 + i;           // k[i] = key[a0 - 1 + i]
-    k[i] = (a >= 1 && a - 1 < A) ? key[a - 1] : ~0ull;
+  __shared__ uint64_t sk[RS_TILE + 2];
+  __shared__ uint64_t m_nh[64], m_sg[64];
+  __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
+  const uint32_t tile = xcd_tile(blockIdx.x, T);
+  if (tile >= T) return;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const uint64_t base = (uint64_t)tile * RS_TILE;
+  const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    sk[e + 1] = e < nvalid ? key[base + e] : ~0ull;
   }
-  uint32_t nhm = 0, sgm = 0, surv = 0, heads = 0, last = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const uint64_t a = a0 + i;
-    if (a < A) {
-      const bool nh = a == 0 || k[i] != k[i + 1];
-      const bool nx = a + 1 == A || k[i + 2] != k[i + 1];
-      const bool single = nh && nx;
-      nhm |= (uint32_t)nh << i; sgm |= (uint32_t)single << i;
-      surv += !single; heads += nh && !single;
-      if (nh) last = (uint32_t)a + 1u;
-    }
+  if (tid == 0) {
+    sk[0] = base ? key[base - 1] : ~0ull;
+    sk[RS_TILE + 1] = base + RS_TILE < A ? key[base + RS_TILE] : ~0ull;
   }
-  uint32_t tot;
-  const uint32_t sbase = tile_cnt[tile] + block_excl_sum<256>(surv, sm, tot);
-  const uint32_t hbase = tile_cnt[T + tile] + block_excl_sum<256>(heads, sm, tot);
-  const uint32_t im = block_incl_max<256>(last, sm);
-  mx[threadIdx.x] = im;
   __syncthreads();
-  uint32_t cur = threadIdx.x ? mx[threadIdx.x - 1] : 0u;
-  const uint32_t carry = tile_cnt[2 * (size_t)T + tile];
-  cur = cur > carry ? cur : carry;      // (index of the governing head)+1
-  uint32_t so = sbase, ho = hbase;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const uint64_t a = a0 + i;
-    if (a < A) {
-      if ((nhm >> i) & 1u) cur = (uint32_t)a + 1u;
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    const uint64_t a = base + e;
+    const bool ok = e < nvalid;
+    const uint64_t k = sk[e + 1];
+    const bool nh = ok && (a == 0 || sk[e] != k);
+    const bool nx = a + 1 == A || sk[e + 2] != k;
+    const uint64_t mnh = __ballot(nh), msg = __ballot(nh && nx);
+    if (lane == 0) { m_nh[it * 4 + w] = mnh; m_sg[it * 4 + w] = msg; }
+  }
+  __syncthreads();
+  if (w == 0) {                          // 64 mask words, one per lane
+    const uint64_t mh = m_nh[lane], ms = m_sg[lane];
+    const uint32_t first = (uint32_t)lane * 64u;
+    const uint32_t nv = nvalid > first ? (nvalid - first < 64u ? nvalid - first : 64u) : 0u;
+    const uint64_t vm = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
+    const uint32_t sv = (uint32_t)__popcll(vm & ~ms), hd = (uint32_t)__popcll(mh & ~ms);
+    const uint32_t lastrel = mh ? first + 63u - (uint32_t)__builtin_clzll(mh) + 1u : 0u;
+    const uint32_t is = wave_incl_sum(sv), ih = wave_incl_sum(hd), im = wave_incl_max(lastrel);
+    uint32_t em = __shfl_up(im, 1, 64);
+    if (lane == 0) em = 0;
+    wp_s[lane] = is - sv; wp_h[lane] = ih - hd; wp_head[lane] = em;
+  }
+  __syncthreads();
+  const uint32_t sbase = tile_cnt[tile], hbase = tile_cnt[T + tile], carry = tile_cnt[2 * (size_t)T + tile];
+  const uint64_t lt = (1ull << lane) - 1ull, le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    if (e < nvalid) {
+      const uint64_t a = base + e;
+      const int wi = it * 4 + w;
+      const uint64_t mh = m_nh[wi], ms = m_sg[wi];
+      const uint64_t hm = mh & le;
+      uint32_t head_a;                    // global index of the governing group head
+      if (hm) head_a = (uint32_t)base + (uint32_t)wi * 64u + 63u - (uint32_t)__builtin_clzll(hm);
+      else head_a = wp_head[wi] ? (uint32_t)base + wp_head[wi] - 1u : carry - 1u;
       const uint32_t p = pos[a], vv = val[a];
       const uint32_t blk = p / g.stride;
-      const uint32_t head_pos = p - ((uint32_t)a - (cur - 1u));
+      const uint32_t head_pos = p - ((uint32_t)a - head_a);
       R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
-      if ((sgm >> i) & 1u) SA[p] = vv;
+      if ((ms >> lane) & 1ull) SA[p] = vv;
       else {
-        if ((nhm >> i) & 1u) ho++;
+        const uint32_t so = sbase + wp_s[wi] + (uint32_t)__popcll(~ms & lt);
+        const uint32_t ho = hbase + wp_h[wi] + (uint32_t)__popcll(mh & ~ms & le);
         nval[so] = vv; npos[so] = p; ngord[so] = ho - 1u;
-        so++;
       }
     }
   }
@@ -291,12 +330,13 @@ __global__ __launch_bounds__(256) void bwt_flush_active(uint32_t A, const uint32
 
 // primary index.  cyclic: last row of the group of rotation 0 (equal rotations are ordered by
 // descending start, J/Bzip2_joined_.js:957-968); sentinel: (row of suffix 0)+1
-__global__ __launch_bounds__(256) void bwt_pidx(Geom g, int cyclic, const uint32_t* __restrict__ R, uint32_t* __restrict__ pidx) {
+__global__ __launch_bounds__(256) void bwt_pidx(Geom g, int cyclic, int leftover, const uint32_t* __restrict__ R, uint32_t* __restrict__ pidx) {
   __shared__ uint32_t sm[4];
   const uint32_t blk = blockIdx.x, n = blk_len(g, blk);
   const uint32_t* r = R + (size_t)blk * g.stride;
   const uint32_t r0 = r[0];
   if (!cyclic) { if (threadIdx.x == 0) pidx[blk] = r0 + 1u; return; }
+  if (!leftover) { if (threadIdx.x == 0) pidx[blk] = r0; return; }     // every rotation is unique
   uint32_t cnt = 0;
   for (uint32_t i = threadIdx.x; i < n; i += 256) cnt += r[i] == r0;
   cnt = block_sum<256>(cnt, sm);
@@ -322,6 +362,7 @@ __global__ __launch_bounds__(256) void bwt_emit(const uint8_t* __restrict__ T, G
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
+static int bits_for(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 size_t BwtWork::bytes_needed(size_t cap) {
   const size_t T = (cap + RS_TILE - 1) / RS_TILE + 1;
   size_t b = 0;
@@ -346,8 +387,6 @@ int BwtWork::carve(Arena& a, size_t cap_) {
   return 0;
 }
 
-static int bits_for(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
-
 struct LaunchTimes {   // event pairs around the dominant kernel; resolved after the stream has drained
   static constexpr int MAXP = 512;
   hipEvent_t ev[2 * MAXP];
@@ -370,15 +409,17 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
   }
 };
 
-static int radix_sort(hipStream_t s, BwtWork& w, int& cur, uint32_t n, int bits, LaunchTimes& lt) {
+template <typename K>
+static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
+                        LaunchTimes* lt) {
   const uint32_t T = (n + RS_TILE - 1) / RS_TILE;
-  for (int shift = 0; shift < bits; shift += 8) {
-    hipLaunchKernelGGL(rs_hist, dim3(T), dim3(256), 0, s, w.key[cur], n, shift, w.hist, T);
+  K* kk[2] = {k0, k1}; uint32_t* vv[2] = {v0, v1};
+  for (int shift = lo_bit; shift < hi_bit; shift += 8) {
+    hipLaunchKernelGGL(rs_hist<K>, dim3(T), dim3(256), 0, s, kk[cur], n, shift, w.hist, T);
     hipLaunchKernelGGL(rs_scan_bins, dim3(256), dim3(1024), 0, s, w.hist, T, w.bintot);
-    lt.begin(s, n);
-    hipLaunchKernelGGL(rs_scatter, dim3(T), dim3(256), 0, s, w.key[cur], w.val[cur], w.key[1 - cur], w.val[1 - cur], n, shift,
-                       w.hist, T, w.bintot);
-    lt.end(s);
+    if (lt) lt->begin(s, n);
+    hipLaunchKernelGGL(rs_scatter<K>, dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], n, shift, w.hist, T, w.bintot);
+    if (lt) lt->end(s);
     cur = 1 - cur;
   }
   CJS_HIP_TRY(hipGetLastError());
@@ -398,20 +439,25 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   LaunchTimes lt; lt.enabled = stats != nullptr;
 
   int c = 0, pc = 0;        // current key/val buffer, current pos buffer
-  hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, M, w.key[0], w.val[0], w.pos[0]);
-  uint32_t A = M, h = 4, rounds = 0;
-  int bits = (cyclic ? 32 : 36) + bits_for(nb - 1);
+  // round 0 sorts by as many leading symbols as fit beside the block id in 64 bits
+  const int blk_bits = bits_for(nb - 1), sym_bits = cyclic ? 8 : 9;
+  int nsym = (64 - blk_bits) / sym_bits;
+  if (nsym > 7) nsym = 7;
+  hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0], w.pos[0]);
+  uint32_t A = M, h = (uint32_t)nsym, rounds = 0;
+  int bits = nsym * sym_bits + blk_bits;
   for (;;) {
-    CJS_TRY(radix_sort(s, w, c, A, bits, lt));
+    CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters);
-    hipLaunchKernelGGL(bwt_apply, dim3(T), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+    hipLaunchKernelGGL(bwt_apply, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                        w.val[1 - c], w.pos[1 - pc], w.gord);
     CJS_HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters, 8, hipMemcpyDeviceToHost, s));
     CJS_HIP_TRY(hipStreamSynchronize(s));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
+    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt] round %u h=%u A=%u bits=%d -> A'=%u groups=%u\n", rounds, h, A, bits, A2, NG);
     c = 1 - c; pc = 1 - pc;
     A = A2;
     if (A == 0) break;
@@ -420,11 +466,14 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
       break;
     }
     if (rounds > 40) return CJS_E_HIP;    // cannot happen: depth doubles every round
-    hipLaunchKernelGGL(bwt_gather_keys, dim3((A + 255) / 256), dim3(256), 0, s, g, (int)cyclic, A, h, w.R, w.val[c], w.pos[pc], w.gord, w.key[c]);
+    {
+      const uint32_t Tg = (A + RS_TILE - 1) / RS_TILE;
+      hipLaunchKernelGGL(bwt_gather_keys, dim3(xcd_grid(Tg)), dim3(256), 0, s, g, (int)cyclic, A, h, w.R, w.val[c], w.pos[pc], w.gord, w.key[c], Tg);
+    }
     h = h < (1u << 29) ? h * 2 : h;
     bits = 20 + bits_for(NG ? NG - 1 : 0);
   }
-  hipLaunchKernelGGL(bwt_pidx, dim3(nb), dim3(256), 0, s, g, (int)cyclic, w.R, d_pidx);
+  hipLaunchKernelGGL(bwt_pidx, dim3(nb), dim3(256), 0, s, g, (int)cyclic, (int)(A != 0), w.R, d_pidx);
   hipLaunchKernelGGL(bwt_emit, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, M, w.SA, w.R, d_U);
   CJS_HIP_TRY(hipGetLastError());
   if (stats) {

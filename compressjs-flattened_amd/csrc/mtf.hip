@@ -35,8 +35,8 @@ __global__ __launch_bounds__(1024) void mtf_heads(const uint8_t* __restrict__ U,
     if (f) mb.alist[(size_t)blk * 256 + ex] = (uint8_t)threadIdx.x;
     if (threadIdx.x == 0) mb.asz[blk] = tot;
   }
-  uint32_t* hpos = mb.hpos + (size_t)blk * stride;
-  uint8_t* hsym = mb.hsym + (size_t)blk * stride;
+  uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
+  uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
   uint32_t carry = 0;
   for (uint32_t base = 0; base < n; base += 4096) {
     const uint32_t p0 = base + threadIdx.x * 4;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(1024) void mtf_chunk_lists(uint32_t stride, MtfBufs
   __shared__ int keys[256];
   __shared__ uint32_t part[4][256];
   const uint32_t blk = blockIdx.x, H = mb.nheads[blk], asz = mb.asz[blk];
-  const uint8_t* hsym = mb.hsym + (size_t)blk * stride;
+  const uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
   uint8_t* lists = mb.lists + (size_t)blk * mb.list_stride;
   if (threadIdx.x < 256) keys[threadIdx.x] = -1000;
   __syncthreads();
@@ -100,26 +100,37 @@ __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= nch) return;
   if (c >= nch) return;
-  const uint8_t* hsym = mb.hsym + (size_t)blk * stride;
-  uint8_t* hrank = mb.hrank + (size_t)blk * stride;
+  const uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
+  uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
   const uint8_t* lst = mb.lists + (size_t)blk * mb.list_stride + (size_t)c * 256;
   uint8_t* my = L + threadIdx.x * LROW;
   for (uint32_t j = 0; j < asz; j++) my[j] = lst[j];
   const uint32_t h0 = c * MTF_CHUNK, h1 = h0 + MTF_CHUNK < H ? h0 + MTF_CHUNK : H;
-  for (uint32_t h = h0; h < h1; h++) {
-    const uint8_t s = hsym[h];
-    uint8_t prev = my[0];
-    uint32_t r = 0;
-    if (prev != s) {
-      my[0] = s;
-      for (r = 1; r < asz; r++) {
-        const uint8_t x = my[r];
-        my[r] = prev;
-        prev = x;
-        if (x == s) break;
+  // 16 heads at a time: one 16-byte load of symbols, one 16-byte store of ranks per lane (hsym/hrank rows
+  // are 256-byte aligned: h0 is a multiple of 256 and the per-block stride is padded to 16)
+  for (uint32_t hb = h0; hb < h1; hb += 16) {
+    uint4 sv = *reinterpret_cast<const uint4*>(hsym + hb);
+    uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w}, rw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const uint32_t h = hb + q;
+      uint32_t r = 0;
+      if (h < h1) {
+        const uint8_t s8 = (uint8_t)(sw[q >> 2] >> (8 * (q & 3)));
+        uint8_t prev = my[0];
+        if (prev != s8) {
+          my[0] = s8;
+          for (r = 1; r < asz; r++) {
+            const uint8_t x = my[r];
+            my[r] = prev;
+            prev = x;
+            if (x == s8) break;
+          }
+        }
       }
+      rw[q >> 2] |= r << (8 * (q & 3));
     }
-    hrank[h] = (uint8_t)r;
+    *reinterpret_cast<uint4*>(hrank + hb) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
   }
 }
 
@@ -128,8 +139,8 @@ __global__ __launch_bounds__(1024) void mtf_emit(uint32_t stride, const uint32_t
   __shared__ uint32_t freq[258];
   __shared__ uint32_t sm[16];
   const uint32_t blk = blockIdx.x, n = blen[blk], H = mb.nheads[blk], asz = mb.asz[blk];
-  const uint32_t* hpos = mb.hpos + (size_t)blk * stride;
-  const uint8_t* hrank = mb.hrank + (size_t)blk * stride;
+  const uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
+  const uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
   uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
   for (int i = threadIdx.x; i < 258; i += 1024) freq[i] = 0;
   __syncthreads();
@@ -173,16 +184,16 @@ __global__ __launch_bounds__(1024) void mtf_emit(uint32_t stride, const uint32_t
 size_t MtfWork::bytes_needed(size_t max_blocks, uint32_t stride) {
   size_t b = 0;
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
-  const size_t ls = list_stride_for(stride), as = a_stride_for(stride);
-  add(max_blocks * stride * 4); add(max_blocks * stride); add(max_blocks * stride); add(max_blocks * ls);
+  const size_t ls = list_stride_for(stride), as = a_stride_for(stride), hs = hstride_for(stride);
+  add(max_blocks * hs * 4); add(max_blocks * hs); add(max_blocks * hs); add(max_blocks * ls);
   add(max_blocks * as * 2); add(max_blocks * 258 * 4); add(max_blocks * 256);
   add(max_blocks * 4); add(max_blocks * 4); add(max_blocks * 4);
   return b + 4096;
 }
 int MtfWork::carve(Arena& a, size_t max_blocks_, uint32_t stride_) {
   max_blocks = max_blocks_; stride = stride_;
-  b.list_stride = list_stride_for(stride); b.a_stride = a_stride_for(stride);
-  b.hpos = a.take<uint32_t>(max_blocks * stride); b.hsym = a.take<uint8_t>(max_blocks * stride); b.hrank = a.take<uint8_t>(max_blocks * stride);
+  b.list_stride = list_stride_for(stride); b.a_stride = a_stride_for(stride); b.hstride = hstride_for(stride);
+  b.hpos = a.take<uint32_t>(max_blocks * b.hstride); b.hsym = a.take<uint8_t>(max_blocks * b.hstride); b.hrank = a.take<uint8_t>(max_blocks * b.hstride);
   b.lists = a.take<uint8_t>(max_blocks * b.list_stride);
   b.A = a.take<uint16_t>(max_blocks * b.a_stride); b.freq = a.take<uint32_t>(max_blocks * 258); b.alist = a.take<uint8_t>(max_blocks * 256);
   b.asz = a.take<uint32_t>(max_blocks); b.nheads = a.take<uint32_t>(max_blocks); b.npos = a.take<uint32_t>(max_blocks);

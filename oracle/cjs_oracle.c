@@ -420,36 +420,57 @@ static int compress_block(const uint8_t *block, int n, bitw_t *w) {
   return w->b->oom ? CJSO_OUT_OF_MEMORY : 0;
 }
 
-int cjs_oracle_bzip2_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n) {
+/* Block loop of Bzip2.compressFile (Bzip2:2199-2249).  framed: 'BZh'+level header and trailer are written and
+ * all blocks are emitted; otherwise only blocks [first, first+count) are emitted as a bare bit string that
+ * starts at bit 0 (what one rank of a sharded job produces).  crcs (optional) receives every block's CRC. */
+static int bzip2_blocks(const uint8_t *in, size_t n, int level, int framed, long first, long count, buf_t *b,
+                        uint64_t *out_bits, uint32_t *crcs, long crc_cap, long *total_blocks) {
   if (level < 1 || level > 9) return CJSO_BAD_LEVEL;                 /* Bzip2:2208 */
   int block_size = level * 100000 - 19;                              /* Bzip2:2212-2220 */
-  buf_t b = {0, 0, 0, 0};
-  bitw_t w = {&b, 0, 0};
-  buf_put(&b, 'B'); buf_put(&b, 'Z'); buf_put(&b, 'h'); buf_put(&b, '0' + level);
+  bitw_t w = {b, 0, 0};
+  if (framed) { buf_put(b, 'B'); buf_put(b, 'Z'); buf_put(b, 'h'); buf_put(b, '0' + level); }
   uint8_t *block = (uint8_t *)malloc((size_t)block_size);
   if (!block) return CJSO_OUT_OF_MEMORY;
   uint32_t stream_crc = 0;
   size_t cursor = 0;
   int length, rc = 0;
+  long k = 0;
   do {                                                               /* Bzip2:2233-2242 */
     uint32_t crc;
     length = cjs_oracle_rle1_block(in, n, &cursor, block, block_size, &crc);
     if (length > 0) {
       stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ crc;
-      bw_bits(&w, 48, 0x314159265359ull);
-      bw_bits(&w, 32, crc);
-      rc = compress_block(block, length, &w);
-      if (rc) break;
+      if (crcs && k < crc_cap) crcs[k] = crc;
+      if (framed || (k >= first && (count < 0 || k < first + count))) {
+        bw_bits(&w, 48, 0x314159265359ull);
+        bw_bits(&w, 32, crc);
+        rc = compress_block(block, length, &w);
+        if (rc) break;
+      }
+      k++;
     }
   } while (length == block_size);
   free(block);
-  if (rc) { free(b.p); return rc; }
-  bw_bits(&w, 48, 0x177245385090ull);
-  bw_bits(&w, 32, stream_crc);
+  if (rc) return rc;
+  if (total_blocks) *total_blocks = k;
+  if (framed) { bw_bits(&w, 48, 0x177245385090ull); bw_bits(&w, 32, stream_crc); }
+  if (out_bits) *out_bits = (uint64_t)b->n * 8 + (uint64_t)w.nacc;
   bw_flush(&w);
-  if (b.oom) { free(b.p); return CJSO_OUT_OF_MEMORY; }
+  return b->oom ? CJSO_OUT_OF_MEMORY : 0;
+}
+int cjs_oracle_bzip2_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n) {
+  buf_t b = {0, 0, 0, 0};
+  int rc = bzip2_blocks(in, n, level, 1, 0, -1, &b, 0, 0, 0, 0);
+  if (rc) { free(b.p); return rc; }
   *out = b.p; *out_n = b.n;
-  if (!b.p) *out = (uint8_t *)malloc(1);
+  return 0;
+}
+int cjs_oracle_bzip2_compress_range(const uint8_t *in, size_t n, int level, long first, long count, uint8_t **out,
+                                    uint64_t *out_bits, uint32_t *crcs, long crc_cap, long *total_blocks) {
+  buf_t b = {0, 0, 0, 0};
+  int rc = bzip2_blocks(in, n, level, 0, first, count, &b, out_bits, crcs, crc_cap, total_blocks);
+  if (rc) { free(b.p); return rc; }
+  *out = b.p ? b.p : (uint8_t *)malloc(1);
   return 0;
 }
 

@@ -32,6 +32,9 @@ extern "C" {
 
 /* whole streams */
 int cjs_oracle_bzip2_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n);
+/* blocks [first, first+count) only, as a bare bit string from bit 0 (no header / trailer); crcs[] gets every block's CRC */
+int cjs_oracle_bzip2_compress_range(const uint8_t *in, size_t n, int level, long first, long count, uint8_t **out,
+                                    uint64_t *out_bits, uint32_t *crcs, long crc_cap, long *total_blocks);
 int cjs_oracle_bzip2_decompress(const uint8_t *in, size_t n, int multistream, uint8_t **out, size_t *out_n);
 int cjs_oracle_bwtc_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n);
 int cjs_oracle_bwtc_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);

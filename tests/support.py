@@ -69,6 +69,8 @@ class Oracle(_StreamLib):
         L.cjs_oracle_rle1_block.argtypes = [V, S, ctypes.POINTER(S), V, I, ctypes.POINTER(ctypes.c_uint32)]
         L.cjs_oracle_mtf_rle2.argtypes = [V, V, I, V, V, ctypes.POINTER(I)]
         L.cjs_oracle_huff_groups.argtypes = [V, I, I, V, V]
+        L.cjs_oracle_bzip2_compress_range.argtypes = [u8p, S, I, ctypes.c_long, ctypes.c_long, ctypes.POINTER(u8p),
+                                                      ctypes.POINTER(ctypes.c_uint64), V, ctypes.c_long, ctypes.POINTER(ctypes.c_long)]
 
     def _free(self, p):
         self.L.cjs_oracle_free(p)
@@ -78,6 +80,21 @@ class Oracle(_StreamLib):
 
     def bzip2_decompress(self, data, multistream=0):
         return self._call_stream(self.L.cjs_oracle_bzip2_decompress, self._free, data, multistream)
+
+    def bzip2_compress_range(self, data, level, first, count, crc_cap=1 << 16):
+        """bare bit string of blocks [first, first+count): (bytes, nbits, total_blocks, all block crcs)"""
+        data = as_u8(data)
+        keep = data if data.size else np.zeros(1, dtype=np.uint8)
+        out, bits, tot = u8p(), ctypes.c_uint64(0), ctypes.c_long(0)
+        crcs = np.zeros(crc_cap, dtype=np.uint32)
+        rc = self.L.cjs_oracle_bzip2_compress_range(keep.ctypes.data_as(u8p), data.size, level, first, count, ctypes.byref(out),
+                                                    ctypes.byref(bits), crcs.ctypes.data, crc_cap, ctypes.byref(tot))
+        if rc:
+            return rc, None, 0, 0, None
+        nb = (bits.value + 7) // 8
+        arr = np.ctypeslib.as_array(out, shape=(max(nb, 1),))[:nb].copy()
+        self.L.cjs_oracle_free(out)
+        return 0, arr, bits.value, tot.value, crcs[: tot.value].copy()
 
     def bwtc_compress(self, data, level=9):
         return self._call_stream(self.L.cjs_oracle_bwtc_compress, self._free, data, level)
