@@ -43,6 +43,12 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libcjs_hip.so not built: run `make hip` / `python __graft_entry__.py` (no CPU fallback exists)")
+    try:
+        # torch wheels bundle their own libamdhip64: load it first so that both share ONE HIP runtime in this
+        # process (two copies of the runtime cannot both own the device)
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     S, I, V = ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p
     PS, PP = ctypes.POINTER(S), ctypes.POINTER(u8p)

@@ -9,6 +9,11 @@ import sys
 
 import pytest
 
+try:   # one HIP runtime per process: torch's bundled copy must be loaded before libcjs_hip.so (see package __init__)
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
