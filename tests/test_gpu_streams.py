@@ -85,3 +85,24 @@ def test_js_front_matches_goldens():
     assert api["sink_returned"] is True and api["sink_hex"] == banana and api["default_level"] == banana
     assert api["level0"] == "Invalid block size multiplier"
     assert api["short_out"] == "TypeError:outputsize does not match decoded input"
+
+
+def _bwtc_cases():
+    g = support.load_golden("golden_small.json")
+    return [c for c in g["cases"] if c["algo"] == "BWTC"]
+
+
+@pytest.mark.parametrize("case", _bwtc_cases(), ids=lambda c: "%s-%d" % (c["name"], c["level"]))
+def test_bwtc_compress_golden(hip, case):
+    data = recipes.build(case["recipe"])
+    rc, out = hip.bwtc_compress(data, case["level"])
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == case["out_len"], "length %d want %d" % (out.size, case["out_len"])
+    assert support.sha256(out) == case["out_sha256"]
+
+
+def test_bwtc_10m_golden(hip):
+    case = support.load_golden("golden_big_bwtc_9_10m.json")["cases"][0]
+    data = recipes.build(case["recipe"])
+    rc, out = hip.bwtc_compress(data, 9)
+    assert rc == 0 and out.size == case["out_len"] and support.sha256(out) == case["out_sha256"]
