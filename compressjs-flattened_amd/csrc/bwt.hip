@@ -426,6 +426,13 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
   return 0;
 }
 
+// 32-bit-key variant for other stages (decode.hip: stable partition of the BWT bytes = LF vector build)
+template <typename K>
+int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit) {
+  return radix_passes<K>(s, w, k0, v0, k1, v1, cur, n, lo_bit, hi_bit, nullptr);
+}
+template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, int, int);
+
 int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t stride, uint32_t n_last,
             bool cyclic, uint8_t* d_U, uint32_t* d_pidx, cjs_stats* stats) {
   if (nb == 0) return 0;

@@ -1,0 +1,616 @@
+// decode.hip — Bzip2.decompressFile (Bunzip.decode, J/Bzip2_joined_.js:1769-1796) on the MI355X.
+//
+// The reference decodes block after block from one bit cursor.  Blocks carry no length field, so here:
+//   1. bz_magic_scan     every bit offset of the stream is tested against the 48-bit block / end-of-stream
+//                        magics (:1434-1439) -> candidate list (a few hundred entries);
+//   2. bz_decode_block   one wave per candidate: header, selector list, code-length tables, then the
+//                        bit-serial Huffman + RUNA/RUNB + MTF decode (:1456-1670) on lane 0 with
+//                        10-bit direct lookup tables built by the whole wave from the reference's
+//                        limit/base/permute semantics; yields the BWT bytes, their histogram, the end bit;
+//   3. host              walks the chain 32 -> end(block0) -> end(block1) ... over the candidates (a false
+//                        2^-48 candidate inside payload bits is simply never reached), folds CRCs;
+//   4. inverse BWT       T vector by a stable radix pass keyed (block, byte) (:1677-1690), then the LF walk
+//                        (:1732-1737) — n dependent gathers — made k-way parallel by splitter list ranking:
+//                        every 128th slot is a splitter, lanes walk to the next splitter, one lane per block
+//                        ranks the splitters, lanes re-walk writing bytes at their final offsets;
+//   5. RLE1 expansion    (:1738-1753) parsed in parallel: a count byte follows 4 equal literals; inside a
+//                        stretch of equal bytes the literal/count phase has period 5 and the only carried
+//                        state (does the stretch start with a count byte?) is a 2-state function scan;
+//   6. CRC check         per block over the output bytes (rle1.hip's slice + GF(2) combine), :1756-1761.
+#include "cjs_internal.h"
+#include "prims.hpp"
+#include "rle1.h"
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace cjs {
+int select_device(const cjs_opts* opts);
+template <typename K>
+int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit);
+int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, const uint32_t* d_nblocks, uint32_t count, uint32_t max_segs,
+               uint32_t* d_seg_crc, uint32_t* d_crc_out);
+}
+using namespace cjs;
+
+namespace cjs {
+
+constexpr uint64_t MAGIC_BLOCK = 0x314159265359ull, MAGIC_END = 0x177245385090ull;
+constexpr int SPL = 128;                  // one splitter every SPL slots of the LF vector
+
+struct Cand { uint64_t bit; uint32_t kind; uint32_t pad; };      // kind 0 = block, 1 = end of stream
+struct BlockOut {
+  uint64_t end_bit;       // first bit after the block's EOB code
+  uint32_t count;         // decoded BWT bytes (dbufCount)
+  uint32_t orig;          // origPointer
+  uint32_t crc;           // stored block CRC
+  int32_t err;            // 0 or a CJS_E_* code
+};
+
+// ---------------------------------------------------------------- 1. magic scan
+__global__ __launch_bounds__(256) void bz_magic_scan(const uint8_t* __restrict__ in, uint64_t n, Cand* __restrict__ out, uint32_t cap,
+                                                     uint32_t* __restrict__ count) {
+  const uint64_t byte = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (byte + 6 > n) return;
+  uint64_t w = 0;
+  for (int i = 0; i < 7; i++) w = (w << 8) | (byte + i < n ? in[byte + i] : 0);      // 56 bits
+  for (int b = 0; b < 8; b++) {
+    if (byte * 8 + b + 48 > n * 8) break;
+    const uint64_t v = (w >> (8 - b)) & 0xFFFFFFFFFFFFull;
+    if (v == MAGIC_BLOCK || v == MAGIC_END) {
+      const uint32_t idx = atomicAdd(count, 1u);
+      if (idx < cap) { out[idx].bit = byte * 8 + b; out[idx].kind = v == MAGIC_END; out[idx].pad = 0; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 2. block decode (one wave per candidate)
+struct BitReader {
+  const uint8_t* p; uint64_t nbits, pos;
+  __device__ __forceinline__ uint32_t peek(int k) const {          // next k <= 25 bits, zeros past EOF (:149)
+    const uint64_t byte = pos >> 3; const uint64_t nbytes = (nbits + 7) >> 3;
+    uint64_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) w = (w << 8) | (byte + i < nbytes ? p[byte + i] : 0);
+    return (uint32_t)((w >> (40 - (pos & 7) - k)) & ((1u << k) - 1u));
+  }
+  __device__ __forceinline__ uint32_t get(int k) { const uint32_t v = peek(k); pos += k; if (pos > nbits) pos = nbits; return v; }
+};
+
+struct DecShared {
+  uint32_t limit[6][22];
+  uint32_t base[6][22];
+  uint16_t permute[6][260];
+  uint16_t fast[6][1024];          // (sym << 5) | len, 0 = not decodable within 10 bits
+  uint8_t minlen[8], maxlen[8];
+  uint8_t length[6][260];
+  uint8_t selectors[32768];
+  uint8_t mtf[256];
+  uint8_t sym_to_byte[256];
+  uint32_t byte_count[256];
+};
+
+__global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand,
+                                                      uint32_t dbuf_size, uint8_t* __restrict__ tt_all, uint32_t* __restrict__ hist_all,
+                                                      BlockOut* __restrict__ outs) {
+  __shared__ DecShared S;
+  const uint32_t c = blockIdx.x;
+  if (c >= ncand) return;
+  const int lane = lane_id();
+  BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
+  if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
+  uint8_t* tt = tt_all + (size_t)c * dbuf_size;
+  BitReader r{in, n * 8, cands[c].bit + 48};
+  int err = 0;
+  uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0;
+  if (lane == 0) {                                           // header (:1440-1493)
+    bo.crc = r.get(16) << 16; bo.crc |= r.get(16);
+    if (r.get(1)) err = CJS_E_OBSOLETE_INPUT;
+    orig = r.get(24);
+    if (!err && orig > dbuf_size) err = CJS_E_DATA_ERROR;
+    const uint32_t t = r.get(16);
+    for (int i = 0; i < 256; i++) S.sym_to_byte[i] = 0;
+    for (int i = 0; i < 16; i++) if (t & (1u << (15 - i))) {
+      const uint32_t k = r.get(16);
+      for (int j = 0; j < 16; j++) if (k & (1u << (15 - j))) S.sym_to_byte[sym_total++] = (uint8_t)(i * 16 + j);
+    }
+    group_count = r.get(3);
+    if (!err && (group_count < 2 || group_count > 6)) err = CJS_E_DATA_ERROR;
+    n_sel = r.get(15);
+    if (!err && n_sel == 0) err = CJS_E_DATA_ERROR;
+    if (!err) {
+      for (int i = 0; i < 256; i++) S.mtf[i] = 0;
+      for (uint32_t i = 0; i < group_count; i++) S.mtf[i] = (uint8_t)i;
+      for (uint32_t i = 0; i < n_sel && !err; i++) {
+        uint32_t j = 0;
+        while (r.get(1)) { if (j >= group_count) { err = CJS_E_DATA_ERROR; break; } j++; }
+        if (err) break;
+        const uint8_t v = S.mtf[j];
+        for (uint32_t k = j; k > 0; k--) S.mtf[k] = S.mtf[k - 1];
+        S.mtf[0] = v;
+        S.selectors[i] = v;
+      }
+    }
+    if (!err) {                                              // code lengths (:1500-1520)
+      const uint32_t sym_count = sym_total + 2;
+      for (uint32_t g = 0; g < group_count && !err; g++) {
+        int t5 = (int)r.get(5);
+        for (uint32_t i = 0; i < sym_count && !err; i++) {
+          for (;;) {
+            if (t5 < 1 || t5 > 20) { err = CJS_E_DATA_ERROR; break; }
+            if (!r.get(1)) break;
+            if (!r.get(1)) t5++; else t5--;
+          }
+          S.length[g][i] = (uint8_t)t5;
+        }
+      }
+    }
+  }
+  err = __shfl(err, 0, 64);
+  sym_total = __shfl(sym_total, 0, 64); group_count = __shfl(group_count, 0, 64); n_sel = __shfl(n_sel, 0, 64);
+  const uint32_t sym_count = sym_total + 2;
+  __builtin_amdgcn_wave_barrier();
+  if (!err) {
+    // limit / base / permute (:1522-1581): lane g builds group g
+    if ((uint32_t)lane < group_count) {
+      const int g = lane;
+      int mn = S.length[g][0], mx = S.length[g][0];
+      for (uint32_t i = 1; i < sym_count; i++) { const int l = S.length[g][i]; if (l > mx) mx = l; else if (l < mn) mn = l; }
+      S.minlen[g] = (uint8_t)mn; S.maxlen[g] = (uint8_t)mx;
+      int pp = 0; uint16_t temp[21];
+      for (int i = 0; i < 21; i++) temp[i] = 0;
+      for (int i = mn; i <= mx; i++) for (uint32_t s = 0; s < sym_count; s++) if (S.length[g][s] == i) S.permute[g][pp++] = (uint16_t)s;
+      for (uint32_t i = 0; i < sym_count; i++) temp[S.length[g][i]]++;
+      for (int i = 0; i < 22; i++) { S.limit[g][i] = 0; S.base[g][i] = 0; }
+      long long p2 = 0, t2 = 0;
+      for (int i = mn; i < mx; i++) {
+        p2 += temp[i];
+        S.limit[g][i] = (uint32_t)(p2 - 1);
+        p2 <<= 1;
+        t2 += temp[i];
+        S.base[g][i + 1] = (uint32_t)(p2 - t2);
+      }
+      S.limit[g][mx] = (uint32_t)(p2 + temp[mx] - 1);
+      S.base[g][mn] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 10-bit direct tables from the same decode rule (:1605-1616)
+    for (uint32_t g = 0; g < group_count; g++) {
+      const int mn = S.minlen[g], mx = S.maxlen[g];
+      for (int x = lane; x < 1024; x += 64) {
+        uint16_t e = 0;
+        for (int i = mn; i <= 10 && i <= mx; i++) {
+          const uint32_t j = (uint32_t)x >> (10 - i);
+          if (j <= S.limit[g][i]) {
+            const long long jj = (long long)j - (long long)S.base[g][i];
+            if (jj >= 0 && jj < 258) e = (uint16_t)((S.permute[g][jj] << 5) | i);
+            else e = 0x1F;                                   // decodes, but to an out-of-range index: DATA_ERROR
+            break;
+          }
+        }
+        S.fast[g][x] = e;
+      }
+    }
+    for (int i = lane; i < 256; i += 64) { S.byte_count[i] = 0; S.mtf[i] = (uint8_t)i; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint32_t dbuf_count = 0;
+  if (lane == 0 && !err) {                                   // symbol loop (:1597-1670)
+    int32_t run_pos = 0; long long run_t = 0;
+    uint32_t selector = 0; int sym_left = 0, g = 0;
+    for (;;) {
+      if (!(sym_left--)) {
+        sym_left = 49;
+        if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
+        g = S.selectors[selector++];
+        if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
+      }
+      uint32_t next_sym;
+      const uint32_t x = r.peek(10);
+      const uint16_t e = S.fast[g][x];
+      if (e && e != 0x1F) { next_sym = e >> 5; r.pos += e & 31; if (r.pos > r.nbits) r.pos = r.nbits; }
+      else if (e == 0x1F) { err = CJS_E_DATA_ERROR; break; }
+      else {                                                 // long code: the reference's bit-by-bit rule
+        int i = S.minlen[g];
+        long long j = r.get(i);
+        for (;; i++) {
+          if (i > S.maxlen[g]) { err = CJS_E_DATA_ERROR; break; }
+          if (j <= (long long)S.limit[g][i]) break;
+          j = (j << 1) | r.get(1);
+        }
+        if (err) break;
+        j -= (long long)S.base[g][i];
+        if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
+        next_sym = S.permute[g][j];
+      }
+      if (next_sym <= 1) {                                   // RUNA / RUNB
+        if (!run_pos) { run_pos = 1; run_t = 0; }
+        run_t += next_sym == 0 ? (long long)run_pos : 2 * (long long)run_pos;
+        run_pos = (int32_t)((uint32_t)run_pos << 1);
+        continue;
+      }
+      if (run_pos) {
+        run_pos = 0;
+        if ((long long)dbuf_count + run_t > (long long)dbuf_size) { err = CJS_E_DATA_ERROR; break; }
+        const uint8_t uc = S.sym_to_byte[S.mtf[0]];
+        S.byte_count[uc] += (uint32_t)run_t;
+        for (long long q = 0; q < run_t; q++) tt[dbuf_count++] = uc;
+      }
+      if (next_sym > sym_total) break;                        // EOB
+      if (dbuf_count >= dbuf_size) { err = CJS_E_DATA_ERROR; break; }
+      uint32_t k = next_sym - 1;
+      const uint8_t v = S.mtf[k];
+      for (; k > 0; k--) S.mtf[k] = S.mtf[k - 1];
+      S.mtf[0] = v;
+      const uint8_t uc = S.sym_to_byte[v];
+      S.byte_count[uc]++;
+      tt[dbuf_count++] = uc;
+    }
+    if (!err && orig >= dbuf_count) err = CJS_E_DATA_ERROR;    // :1677
+  }
+  __builtin_amdgcn_wave_barrier();
+  err = __shfl(err, 0, 64);
+  if (!err) for (int i = lane; i < 256; i += 64) hist_all[(size_t)c * 256 + i] = S.byte_count[i];
+  if (lane == 0) { bo.end_bit = r.pos; bo.count = dbuf_count; bo.orig = orig; bo.err = err; outs[c] = bo; }
+}
+
+// ---------------------------------------------------------------- 4. inverse BWT
+struct IbBlock {            // per valid block, in stream order
+  uint32_t cand;            // candidate index (tt / hist location)
+  uint32_t count;           // n
+  uint32_t orig;
+  uint32_t off;             // element offset of the block in the concatenated arrays
+  uint64_t out_off;         // byte offset of the block in the final output
+  uint32_t out_len;
+  uint32_t crc;
+};
+
+// keys (block << 8 | byte), vals = i
+__global__ __launch_bounds__(256) void ib_make_keys(const uint8_t* __restrict__ tt_all, uint32_t dbuf_size, const IbBlock* __restrict__ blocks,
+                                                    uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const IbBlock b = blocks[blockIdx.y];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < b.count; i += gridDim.x * 256) {
+    key[b.off + i] = ((uint32_t)blockIdx.y << 8) | tt_all[(size_t)b.cand * dbuf_size + i];
+    val[b.off + i] = i;
+  }
+}
+// after the stable sort: slot j of the block holds (T[j] << 8) | tt[j] == the reference's dbuf (:1686-1690):
+// the pointer comes from the sorted order, the low byte is the j-th DECODED byte (not the sorted one)
+__global__ __launch_bounds__(256) void ib_pack(const uint8_t* __restrict__ tt_all, uint32_t dbuf_size, const IbBlock* __restrict__ blocks,
+                                               const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf) {
+  const IbBlock b = blocks[blockIdx.y];
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < b.count; j += gridDim.x * 256)
+    dbuf[b.off + j] = (val[b.off + j] << 8) | tt_all[(size_t)b.cand * dbuf_size + j];
+}
+// splitters: slot j with j % SPL == 0, plus the start slot.  Walk until the next splitter.
+__device__ __forceinline__ bool is_split(uint32_t j, uint32_t start) { return (j % SPL) == 0 || j == start; }
+__global__ __launch_bounds__(256) void ib_walk1(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t spl_stride,
+                                                uint32_t* __restrict__ spl_next, uint32_t* __restrict__ spl_steps) {
+  const IbBlock b = blocks[blockIdx.y];
+  const uint32_t* d = dbuf + b.off;
+  const uint32_t start = d[b.orig] >> 8;                       // first slot visited by the loop (:1698-1700)
+  const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;         // regular splitters + one slot for `start`
+  for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < nspl; sidx += gridDim.x * 256) {
+    uint32_t pos;
+    if (sidx == nspl - 1) { pos = start; if ((start % SPL) == 0) { spl_steps[(size_t)blockIdx.y * spl_stride + sidx] = 0; spl_next[(size_t)blockIdx.y * spl_stride + sidx] = start / SPL; continue; } }
+    else pos = sidx * SPL;
+    uint32_t steps = 0, cur = pos;
+    do { cur = d[cur] >> 8; steps++; } while (!is_split(cur, start) && steps < b.count);
+    spl_steps[(size_t)blockIdx.y * spl_stride + sidx] = steps;
+    spl_next[(size_t)blockIdx.y * spl_stride + sidx] = (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
+  }
+}
+// rank the splitter chain from `start`: spl_rank[s] = number of output positions before splitter s's segment
+__global__ void ib_rank(const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t spl_stride, const uint32_t* __restrict__ spl_next,
+                        const uint32_t* __restrict__ spl_steps, uint32_t* __restrict__ spl_rank, int32_t* __restrict__ err) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nblocks) return;
+  const IbBlock b = blocks[k];
+  const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;
+  const uint32_t* nx = spl_next + (size_t)k * spl_stride; const uint32_t* st = spl_steps + (size_t)k * spl_stride;
+  uint32_t* rk = spl_rank + (size_t)k * spl_stride;
+  for (uint32_t i = 0; i < nspl; i++) rk[i] = 0xFFFFFFFFu;
+  uint32_t cur = nspl - 1, done = 0;
+  // the start splitter may alias a regular one (start % SPL == 0): its entry has steps 0 and points at it
+  for (uint32_t guard = 0; guard <= nspl + 1 && done < b.count; guard++) {
+    if (rk[cur] != 0xFFFFFFFFu && st[cur] != 0) break;           // back on a visited splitter: the permutation has a short cycle
+    rk[cur] = done; done += st[cur]; cur = nx[cur];
+  }
+  // done < count: the LF permutation has a short cycle (periodic block, e.g. "abab"): the reference keeps walking
+  // round it for `count` steps (:1732), i.e. the byte sequence is periodic with period `done`
+  err[k] = (int32_t)done;
+}
+__global__ __launch_bounds__(256) void ib_periodic_fill(const IbBlock* __restrict__ blocks, const int32_t* __restrict__ cyc, uint8_t* __restrict__ wbuf) {
+  const IbBlock b = blocks[blockIdx.y];
+  const uint32_t L = (uint32_t)cyc[blockIdx.y];
+  if (L == 0 || L >= b.count) return;
+  uint8_t* w = wbuf + b.off;
+  for (uint32_t r = L + blockIdx.x * 256 + threadIdx.x; r < b.count; r += gridDim.x * 256) w[r] = w[r % L];
+}
+// second walk: write the pre-RLE1 byte sequence w[0..n) of each block (w[r] = byte of the (r+1)-th visited slot)
+__global__ __launch_bounds__(256) void ib_walk2(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t spl_stride,
+                                                const uint32_t* __restrict__ spl_rank, const uint32_t* __restrict__ spl_steps,
+                                                uint8_t* __restrict__ wbuf) {
+  const IbBlock b = blocks[blockIdx.y];
+  const uint32_t* d = dbuf + b.off;
+  uint8_t* w = wbuf + b.off;
+  const uint32_t start = d[b.orig] >> 8;
+  const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;
+  for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < nspl; sidx += gridDim.x * 256) {
+    const uint32_t rank = spl_rank[(size_t)blockIdx.y * spl_stride + sidx], steps = spl_steps[(size_t)blockIdx.y * spl_stride + sidx];
+    if (rank == 0xFFFFFFFFu || steps == 0) continue;
+    uint32_t cur = sidx == nspl - 1 ? start : sidx * SPL;
+    // visiting order: position `rank` of the walk is slot `cur`; the loop outputs the byte of every visited slot (:1735-1736)
+    for (uint32_t q = 0; q < steps && rank + q < b.count; q++) {
+      const uint32_t e = d[cur];
+      w[rank + q] = (uint8_t)(e & 0xFF);
+      cur = e >> 8;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 5. RLE1 expansion
+// Stretch functions on the carried bit c0 ("this stretch starts with a count byte"): next = ((L - c0) % 5 == 4)
+//   L % 5 == 4 -> NOT-ish (c0=0 ->1, c0=1 -> 0), L % 5 == 0 -> identity, else const 0.  Encoded as 2 bits (f(0) | f(1) << 1).
+__device__ __forceinline__ uint32_t stretch_fn(uint32_t L) { const uint32_t m = L % 5; return m == 4 ? 1u : (m == 0 ? 2u : 0u); }
+__device__ __forceinline__ uint32_t fn_apply(uint32_t f, uint32_t c) { return (f >> c) & 1u; }
+__device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) {     // x -> then(first(x))
+  return fn_apply(then, fn_apply(first, 0)) | (fn_apply(then, fn_apply(first, 1)) << 1);
+}
+// One workgroup per block, sequential 4096-byte tiles.  mode 0: count output bytes -> out_len; mode 1: write.
+__global__ __launch_bounds__(1024) void unrle1(const uint8_t* __restrict__ wbuf, IbBlock* __restrict__ blocks, uint8_t* __restrict__ out, int mode) {
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t fnarr[1024];
+  __shared__ uint32_t posarr[1024];
+  IbBlock b = blocks[blockIdx.x];
+  const uint8_t* w = wbuf + b.off;
+  const uint32_t n = b.count;
+  uint8_t* o = out + b.out_off;
+  // carried across tiles: start of the current stretch, c0 of the current stretch, output bytes so far
+  uint32_t cur_start = 0, cur_c0 = 0, out_base = 0;
+  for (uint32_t base = 0; base < n; base += 4096) {
+    const uint32_t p0 = base + threadIdx.x * 4;
+    uint8_t c[5]; c[0] = (p0 > 0 && p0 - 1 < n) ? w[p0 - 1] : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j + 1] = p0 + j < n ? w[p0 + j] : 0;
+    // stretch boundaries inside my 4 positions
+    uint32_t bmask = 0, lastb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const uint32_t p = p0 + j; if (p < n && p > 0 && c[j + 1] != c[j]) { bmask |= 1u << j; lastb = p + 1; } }
+    // previous boundary before my first position: max-scan of (boundary position + 1), 0 = none in this tile
+    const uint32_t im = block_incl_max<1024>(lastb, sm);
+    posarr[threadIdx.x] = im;
+    __syncthreads();
+    const uint32_t exb = threadIdx.x ? posarr[threadIdx.x - 1] : 0u;
+    const uint32_t tile_last = posarr[1023];
+    __syncthreads();
+    // per-thread function = composition of the stretch functions of the boundaries in my 4 positions (in order);
+    // a boundary at p closes the stretch [prev_start, p) of length p - prev_start
+    uint32_t f = 2u;   // identity
+    {
+      uint32_t ps = exb ? exb - 1 : cur_start;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if ((bmask >> j) & 1u) { const uint32_t p = p0 + j; f = fn_compose(f, stretch_fn(p - ps)); ps = p; }
+    }
+    // exclusive scan of function composition across threads (serial over 16 waves via LDS is fine: 1024 entries)
+    fnarr[threadIdx.x] = f;
+    __syncthreads();
+    // Hillis-Steele inclusive scan in LDS
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      const uint32_t mine = fnarr[threadIdx.x];
+      const uint32_t other = threadIdx.x >= d ? fnarr[threadIdx.x - d] : 2u;
+      __syncthreads();
+      fnarr[threadIdx.x] = fn_compose(other, mine);
+      __syncthreads();
+    }
+    const uint32_t fex = threadIdx.x ? fnarr[threadIdx.x - 1] : 2u;       // composition of all earlier threads' functions
+    const uint32_t fall = fnarr[1023];
+    __syncthreads();
+    // c0 of the stretch governing my first position
+    uint32_t c0 = fn_apply(fex, cur_c0);
+    uint32_t ps = exb ? exb - 1 : cur_start;
+    uint32_t cnt = 0, is_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t p = p0 + j;
+      if (p < n) {
+        if ((bmask >> j) & 1u) { c0 = fn_apply(stretch_fn(p - ps), c0); ps = p; }
+        const uint32_t q = ps + c0;                             // first literal of the stretch
+        const uint32_t rel = p >= q ? p - q : 0u;
+        const uint32_t count_byte = ((p == ps) & c0) | ((p >= q) & ((rel % 5u) == 4u));
+        is_cnt |= count_byte << j;
+        cnt += count_byte ? (uint32_t)c[j + 1] : 1u;
+      }
+    }
+    uint32_t tot;
+    uint32_t off = out_base + block_excl_sum<1024>(cnt, sm, tot);
+    if (mode == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t p = p0 + j;
+        if (p < n) {
+          if ((is_cnt >> j) & 1u) { const uint32_t k = c[j + 1]; const uint8_t v = c[j]; for (uint32_t q = 0; q < k; q++) o[off + q] = v; off += k; }
+          else o[off++] = c[j + 1];
+        }
+      }
+    }
+    out_base += tot;
+    // carry
+    if (tile_last) { cur_c0 = fn_apply(fall, cur_c0); cur_start = tile_last - 1; }
+  }
+  if (mode == 0 && threadIdx.x == 0) blocks[blockIdx.x].out_len = out_base;
+}
+
+__global__ void ib_make_crc_ranges(const IbBlock* __restrict__ blocks, uint32_t nblocks, RleBlock* __restrict__ ranges, uint32_t* __restrict__ nb_dev) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) *nb_dev = nblocks;
+  if (k >= nblocks) return;
+  RleBlock r; r.s = blocks[k].out_off; r.e = blocks[k].out_off + blocks[k].out_len; r.r_end = 0; r.Gr = 0; r.len = 0; r.base = 0;
+  ranges[k] = r;
+}
+
+}  // namespace cjs
+
+// ---------------------------------------------------------------- host driver
+extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
+  if (!out || !out_n) return CJS_E_INVALID_ARG;
+  *out = nullptr; *out_n = 0;
+  CJS_TRY(select_device(opts));
+  // _start_bunzip (:1408-1427)
+  if (n < 4 || in[0] != 'B' || in[1] != 'Z' || in[2] != 'h') return CJS_E_NOT_BZIP_DATA;
+  int level = in[3] - '0';
+  if (level < 1 || level > 9) return CJS_E_NOT_BZIP_DATA;
+  uint32_t dbuf_size = 100000u * (uint32_t)level;
+
+  hipStream_t s = nullptr;
+  uint8_t* d_in = nullptr; Cand* d_cand = nullptr; uint32_t* d_count = nullptr;
+  const uint32_t cand_cap = (uint32_t)(n / 64 + 1024);
+  int rc = 0;
+  std::vector<void*> to_free;
+  auto dmalloc = [&](void** p, size_t bytes) { if (hipMalloc(p, bytes ? bytes : 4) != hipSuccess) return CJS_E_OUT_OF_MEMORY; to_free.push_back(*p); return 0; };
+  auto cleanup = [&]() { for (void* p : to_free) (void)hipFree(p); if (s) (void)hipStreamDestroy(s); };
+  if (hipStreamCreate(&s) != hipSuccess) return CJS_E_HIP;
+  if (!rc) rc = dmalloc((void**)&d_in, n + 16);
+  if (!rc) rc = dmalloc((void**)&d_cand, sizeof(Cand) * cand_cap);
+  if (!rc) rc = dmalloc((void**)&d_count, 64);
+  if (!rc && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemsetAsync(d_count, 0, 64, s) != hipSuccess) rc = CJS_E_HIP;
+  if (rc) { cleanup(); return rc; }
+  hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (uint64_t)n, d_cand, cand_cap, d_count);
+  uint32_t ncand = 0;
+  if (hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
+  if (ncand > cand_cap) { cleanup(); return CJS_E_DATA_ERROR; }
+  std::vector<Cand> cands(ncand);
+  if (ncand && hipMemcpy(cands.data(), d_cand, sizeof(Cand) * ncand, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return CJS_E_HIP; }
+  std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.bit < b.bit; });
+  if (ncand && hipMemcpy(d_cand, cands.data(), sizeof(Cand) * ncand, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return CJS_E_HIP; }
+
+  // speculative decode of every candidate (all stream levels of a multistream input must agree with the first one
+  // for the buffers; the reference asserts the same, :1858)
+  uint8_t* d_tt = nullptr; uint32_t* d_hist = nullptr; BlockOut* d_bo = nullptr;
+  if (!rc) rc = dmalloc((void**)&d_tt, (size_t)(ncand ? ncand : 1) * dbuf_size);
+  if (!rc) rc = dmalloc((void**)&d_hist, (size_t)(ncand ? ncand : 1) * 256 * 4);
+  if (!rc) rc = dmalloc((void**)&d_bo, sizeof(BlockOut) * (ncand ? ncand : 1));
+  if (rc) { cleanup(); return rc; }
+  std::vector<BlockOut> bos(ncand);
+  if (ncand) {
+    hipLaunchKernelGGL(bz_decode_block, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
+    if (hipMemcpyAsync(bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
+  }
+  // chain walk (Bunzip.decode :1776-1794)
+  auto find = [&](uint64_t bit) -> long {
+    size_t lo = 0, hi = cands.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (cands[mid].bit < bit) lo = mid + 1; else hi = mid; }
+    return (lo < cands.size() && cands[lo].bit == bit) ? (long)lo : -1;
+  };
+  auto read_bits = [&](uint64_t bit, int k) -> uint64_t { uint64_t v = 0; for (int i = 0; i < k; i++) { const uint64_t b = bit + i; v = (v << 1) | ((b >> 3) < n ? (in[b >> 3] >> (7 - (b & 7))) & 1u : 0u); } return v; };
+  std::vector<IbBlock> chain;
+  uint64_t pos = 32; uint32_t stream_crc = 0;
+  for (;;) {
+    if ((pos + 7) / 8 >= n) break;                               // inputStream.eof() (:1777)
+    const long ci = find(pos);
+    if (ci < 0) { rc = CJS_E_NOT_BZIP_DATA; break; }             // h !== WHOLEPI (:1438)
+    if (cands[ci].kind == 0) {
+      const BlockOut& bo = bos[ci];
+      if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block at bit %llu: err %d count %u orig %u crc %08x end %llu\n", (unsigned long long)pos, bo.err, bo.count, bo.orig, bo.crc, (unsigned long long)bo.end_bit);
+      if (bo.err) { rc = bo.err; break; }
+      stream_crc = bo.crc ^ ((stream_crc << 1) | (stream_crc >> 31));
+      IbBlock ib; ib.cand = (uint32_t)ci; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
+      chain.push_back(ib);
+      pos = bo.end_bit;
+    } else {
+      const uint32_t target = (uint32_t)read_bits(pos + 48, 32);
+      pos += 80;
+      if ((pos + 7) / 8 > n) pos = (uint64_t)n * 8;
+      if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] end of stream at bit %llu: stream crc %08x stored %08x\n", (unsigned long long)pos - 80, stream_crc, target);
+      if (target != stream_crc) { rc = CJS_E_DATA_ERROR; break; }
+      const uint64_t byte = (pos + 7) / 8;
+      if (multistream && byte < n) {                            // _start_bunzip again, byte aligned (:1787-1792)
+        if (byte + 4 > n || in[byte] != 'B' || in[byte + 1] != 'Z' || in[byte + 2] != 'h') { rc = CJS_E_NOT_BZIP_DATA; break; }
+        const int lv = in[byte + 3] - '0';
+        if (lv < 1 || lv > 9) { rc = CJS_E_NOT_BZIP_DATA; break; }
+        if ((uint32_t)lv * 100000u != dbuf_size) { rc = CJS_E_UNSUPPORTED; break; }
+        pos = (byte + 4) * 8; stream_crc = 0;
+      } else break;
+    }
+  }
+  if (rc) { cleanup(); return rc; }
+  const uint32_t nb = (uint32_t)chain.size();
+  if (nb == 0) { cleanup(); *out = (uint8_t*)malloc(1); *out_n = 0; return *out ? 0 : CJS_E_OUT_OF_MEMORY; }
+
+  // ---- inverse BWT for the chain's blocks
+  uint64_t M64 = 0;
+  for (auto& b : chain) { b.off = (uint32_t)M64; M64 += b.count; }
+  if (M64 >= 0xFFFFF000ull) { cleanup(); return CJS_E_UNSUPPORTED; }
+  const uint32_t M = (uint32_t)M64;
+  IbBlock* d_blocks = nullptr; uint32_t *d_key0 = nullptr, *d_key1 = nullptr, *d_val0 = nullptr, *d_val1 = nullptr, *d_dbuf = nullptr;
+  uint8_t* d_w = nullptr; uint32_t *d_snext = nullptr, *d_ssteps = nullptr, *d_srank = nullptr; int32_t* d_err = nullptr;
+  const uint32_t spl_stride = dbuf_size / SPL + 4;
+  BwtWork sw;
+  if (!rc) rc = dmalloc((void**)&d_blocks, sizeof(IbBlock) * nb);
+  if (!rc) rc = dmalloc((void**)&d_key0, 4 * (size_t)M + 64); if (!rc) rc = dmalloc((void**)&d_key1, 4 * (size_t)M + 64);
+  if (!rc) rc = dmalloc((void**)&d_val0, 4 * (size_t)M + 64); if (!rc) rc = dmalloc((void**)&d_val1, 4 * (size_t)M + 64);
+  if (!rc) rc = dmalloc((void**)&d_w, (size_t)M + 64);
+  if (!rc) rc = dmalloc((void**)&d_snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_ssteps, 4 * (size_t)nb * spl_stride);
+  if (!rc) rc = dmalloc((void**)&d_srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_err, 4 * (size_t)nb);
+  const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
+  if (!rc) rc = dmalloc((void**)&sw.hist, 256 * T * 4); if (!rc) rc = dmalloc((void**)&sw.bintot, 256 * 4);
+  if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemsetAsync(d_err, 0, 4 * (size_t)nb, s) != hipSuccess) rc = CJS_E_HIP;
+  if (rc) { cleanup(); return rc; }
+  d_dbuf = d_key1;   // reuse after the sort (see below)
+  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_tt, dbuf_size, d_blocks, d_key0, d_val0);
+  int cur = 0;
+  int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
+  rc = radix_passes_public<uint32_t>(s, sw, d_key0, d_val0, d_key1, d_val1, cur, M, 0, kbits);
+  if (rc) { cleanup(); return rc; }
+  uint32_t* skey = cur ? d_key1 : d_key0; uint32_t* sval = cur ? d_val1 : d_val0;
+  d_dbuf = cur ? d_key0 : d_key1;                                // the buffer the sort is not sitting in
+  (void)skey;
+  hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, d_tt, dbuf_size, d_blocks, sval, d_dbuf);
+  hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps);
+  hipLaunchKernelGGL(ib_rank, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
+  hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_w);
+  hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, d_blocks, d_err, d_w);
+  hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_w, d_blocks, (uint8_t*)nullptr, 0);
+  std::vector<int32_t> errs(nb);
+  if (hipMemcpyAsync(chain.data(), d_blocks, sizeof(IbBlock) * nb, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
+  for (uint32_t k = 0; k < nb; k++) if (errs[k] <= 0) { cleanup(); return CJS_E_DATA_ERROR; }    // cannot happen: the walk makes >= 1 step
+  uint64_t total = 0;
+  for (auto& b : chain) { b.out_off = total; total += b.out_len; }
+  uint8_t* d_out = nullptr; RleBlock* d_ranges = nullptr; uint32_t *d_nb = nullptr, *d_seg = nullptr, *d_crc = nullptr;
+  const uint32_t max_segs = (uint32_t)(((size_t)dbuf_size * 256 + 16383) / 16384 + 2);
+  uint32_t need_segs = 1;
+  for (auto& b : chain) { const uint32_t sg = (uint32_t)((b.out_len + 16383) / 16384 + 1); if (sg > need_segs) need_segs = sg; }
+  (void)max_segs;
+  if (!rc) rc = dmalloc((void**)&d_out, total + 64);
+  if (!rc) rc = dmalloc((void**)&d_ranges, sizeof(RleBlock) * nb);
+  if (!rc) rc = dmalloc((void**)&d_nb, 64);
+  if (!rc) rc = dmalloc((void**)&d_seg, 4 * (size_t)nb * need_segs);
+  if (!rc) rc = dmalloc((void**)&d_crc, 4 * (size_t)nb);
+  if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  if (rc) { cleanup(); return rc; }
+  hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_w, d_blocks, d_out, 1);
+  hipLaunchKernelGGL(ib_make_crc_ranges, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, d_ranges, d_nb);
+  rc = crc_ranges(s, d_out, d_ranges, d_nb, nb, need_segs, d_seg, d_crc);
+  std::vector<uint32_t> crcs(nb);
+  uint8_t* host = (uint8_t*)malloc(total ? total : 1);
+  if (!rc && !host) rc = CJS_E_OUT_OF_MEMORY;
+  if (!rc && hipMemcpyAsync(crcs.data(), d_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && total && hipMemcpyAsync(host, d_out, total, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) for (uint32_t k = 0; k < nb; k++) if (crcs[k] != chain[k].crc) {                                    // Bad block CRC (:1756-1761)
+    if (getenv("CJS_DEBUG")) {
+      fprintf(stderr, "[cjs dec] block %u: Bad block CRC (got %08x expected %08x) out_len %u:", k, crcs[k], chain[k].crc, chain[k].out_len);
+      for (uint32_t i = 0; i < chain[k].out_len && i < 40; i++) fprintf(stderr, " %02x", host[chain[k].out_off + i]);
+      fprintf(stderr, "\n");
+    }
+    rc = CJS_E_DATA_ERROR; break;
+  }
+  cleanup();
+  if (rc) { free(host); return rc; }
+  *out = host; *out_n = (size_t)total;
+  return 0;
+}

@@ -460,6 +460,16 @@ int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_, size_t range_blocks
   return seg_crc ? 0 : CJS_E_OUT_OF_MEMORY;
 }
 
+// CRC-32 of arbitrary byte ranges [s,e) of d_data (used by the decoder for the per-block output CRCs)
+int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, const uint32_t* d_nblocks, uint32_t count, uint32_t max_segs,
+               uint32_t* d_seg_crc, uint32_t* d_crc_out) {
+  if (!count) return 0;
+  hipLaunchKernelGGL(rle_crc_partial, dim3(max_segs, count), dim3(256), 0, s, d_data, d_blocks, d_nblocks, max_segs, 0u, d_seg_crc);
+  hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, s, d_blocks, d_nblocks, max_segs, 0u, count, d_seg_crc, d_crc_out);
+  CJS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // Stage 0a: block boundaries of the whole stream d_in[0..N).  Leaves descriptors / lengths on the device,
 // returns the number of blocks in *nblocks_host (syncs the stream).
 int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host) {

@@ -106,3 +106,49 @@ def test_bwtc_10m_golden(hip):
     data = recipes.build(case["recipe"])
     rc, out = hip.bwtc_compress(data, 9)
     assert rc == 0 and out.size == case["out_len"] and support.sha256(out) == case["out_sha256"]
+
+
+@pytest.mark.parametrize("name", ["sample0", "sample1", "sample2", "sample3", "sample4"])
+def test_bzip2_decoder_goldens(hip, name):
+    # NPM/test/bzip2-basic.js: streams produced by the real bzip2
+    comp = np.fromfile(os.path.join(recipes.DATA, name + ".bz2"), dtype=np.uint8)
+    ref = np.fromfile(os.path.join(recipes.DATA, name + ".ref"), dtype=np.uint8)
+    rc, out = hip.bzip2_decompress(comp)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == ref.size and np.array_equal(out, ref)
+
+
+def _bz_cases():
+    g = support.load_golden("golden_small.json")
+    return [c for c in g["cases"] if c["algo"] == "Bzip2" and c["level"] in (1, 9)]
+
+
+@pytest.mark.parametrize("case", _bz_cases(), ids=lambda c: "%s-%d" % (c["name"], c["level"]))
+def test_bzip2_decompress_round_trip(hip, oracle, case):
+    data = recipes.build(case["recipe"])
+    rc, comp = oracle.bzip2_compress(data, case["level"])       # == the reference's stream (pinned)
+    assert rc == 0
+    rc, out = hip.bzip2_decompress(comp)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == data.size and np.array_equal(out, data)
+
+
+def test_bzip2_decompress_errors_and_multistream(hip, oracle):
+    assert hip.bzip2_decompress(b"garbage data here")[0] == -2
+    assert hip.bzip2_decompress(b"BZh0")[0] == -2
+    comp = np.fromfile(os.path.join(recipes.DATA, "sample1.bz2"), dtype=np.uint8).copy()
+    comp[2000] ^= 0x10
+    assert hip.bzip2_decompress(comp)[0] == -5
+    a = oracle.bzip2_compress(b"first stream ", 1)[1]
+    b = oracle.bzip2_compress(b"second stream", 1)[1]
+    both = np.concatenate([a, b])
+    assert hip.bzip2_decompress(both, 0)[1].tobytes() == b"first stream "
+    assert hip.bzip2_decompress(both, 1)[1].tobytes() == b"first stream second stream"
+
+
+def test_bzip2_decompress_10m(hip, oracle):
+    data = recipes.textgen(10000000, 1)
+    rc, comp = hip.bzip2_compress(data, 9)
+    assert rc == 0
+    rc, out = hip.bzip2_decompress(comp)
+    assert rc == 0 and np.array_equal(out, data)
