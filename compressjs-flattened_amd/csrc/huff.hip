@@ -106,25 +106,47 @@ struct HuffShared {
   int work[6][260];
   uint8_t lens[6][264];
   uint32_t chist[1024];
+  uint64_t packed[260];
   uint32_t counts[8];
   uint32_t misc[8];
   uint32_t sm[16];
 };
 
-__device__ void assign_selectors(const HuffShared& S, const uint16_t* __restrict__ A, uint32_t npos, uint32_t nsel, int ng,
-                                 uint8_t* __restrict__ sel, uint16_t* __restrict__ bcost) {
-  for (uint32_t g = threadIdx.x; g < nsel; g += 1024) {                             // Bzip2:1989-2004
-    const uint32_t off = g * GSZ, cnt = npos - off < GSZ ? npos - off : GSZ;
-    uint32_t c[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t i = 0; i < cnt; i++) {
-      const uint32_t s = A[off + i];
+// assignSelectors (Bzip2:1989-2004).  Cost of a 50-symbol group under all tables at once: the six code
+// lengths of a symbol are packed as 10-bit fields of one u64 (50 * 20 < 1024, fields cannot overflow), so the
+// inner loop is one LDS read + one 64-bit add per symbol.  Symbols are staged through LDS with coalesced
+// loads (512 groups = 51,200 bytes per step); lane g then reads its 25 dwords at a 25-dword stride (no bank aliasing).
+constexpr int AS_GROUPS = 512;
+__device__ void assign_selectors(HuffShared& S, uint32_t* __restrict__ stage /* AS_GROUPS*25 dwords */, const uint16_t* __restrict__ A,
+                                 uint32_t npos, uint32_t nsel, int ng, uint8_t* __restrict__ sel, uint16_t* __restrict__ bcost) {
+  for (int s = threadIdx.x; s < MAXSYM; s += 1024) {
+    uint64_t pk = 0;
+    for (int j = 0; j < ng; j++) pk |= (uint64_t)S.lens[j][s] << (10 * j);
+    S.packed[s] = pk;
+  }
+  __syncthreads();
+  const uint32_t* A32 = reinterpret_cast<const uint32_t*>(A);          // A rows are 16-byte aligned (a_stride % 8 == 0)
+  const uint32_t ndw = (npos + 1) / 2;
+  for (uint32_t g0 = 0; g0 < nsel; g0 += AS_GROUPS) {
+    const uint32_t dw0 = g0 * 25;
+    for (uint32_t i = threadIdx.x; i < AS_GROUPS * 25; i += 1024) stage[i] = dw0 + i < ndw ? A32[dw0 + i] : 0u;
+    __syncthreads();
+    const uint32_t g = g0 + threadIdx.x;
+    if (threadIdx.x < AS_GROUPS && g < nsel) {
+      const uint32_t off = g * GSZ, cnt = npos - off < GSZ ? npos - off : GSZ;
+      const uint32_t* my = stage + threadIdx.x * 25;
+      uint64_t acc = 0;
+      for (uint32_t i = 0; i < cnt; i += 2) {
+        const uint32_t w = my[i >> 1];
+        acc += S.packed[w & 0xFFFFu];
+        if (i + 1 < cnt) acc += S.packed[w >> 16];
+      }
+      int best = 0; uint32_t bc = (uint32_t)(acc & 1023u);
 #pragma unroll
-      for (int j = 0; j < 6; j++) if (j < ng) c[j] += S.lens[j][s];
+      for (int j = 1; j < 6; j++) { const uint32_t cj = (uint32_t)((acc >> (10 * j)) & 1023u); if (j < ng && cj < bc) { best = j; bc = cj; } }
+      sel[g] = (uint8_t)best; bcost[g] = (uint16_t)bc;
     }
-    int best = 0; uint32_t bc = c[0];
-#pragma unroll
-    for (int j = 1; j < 6; j++) if (j < ng && c[j] < bc) { best = j; bc = c[j]; }
-    sel[g] = (uint8_t)best; bcost[g] = (uint16_t)bc;
+    __syncthreads();
   }
 }
 
@@ -132,6 +154,7 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
                                                    const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
                                                    const uint32_t* __restrict__ freq_all, const uint8_t* __restrict__ alist_all) {
   __shared__ HuffShared S;
+  __shared__ uint32_t stage[AS_GROUPS * 25];
   const uint32_t blk = blockIdx.x;
   const uint32_t npos = npos_all[blk], asz = asz_all[blk];
   const int n = (int)asz + 2;
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
   __syncthreads();
   int ng = 2;
   while (ng < target) {                                                             // Bzip2:2012-2053
-    assign_selectors(S, A, npos, nsel, ng, sel, bcost);
+    assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);
     if (threadIdx.x < 8) S.counts[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t g = threadIdx.x; g < nsel; g += 1024) atomicAdd(&S.counts[sel[g]], 1u);
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
     if (w < ng) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
     __syncthreads();
   }
-  assign_selectors(S, A, npos, nsel, ng, sel, bcost);                               // Bzip2:2163
+  assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);                        // Bzip2:2163
   __syncthreads();
 
   // ---- bit accounting

@@ -13,6 +13,8 @@ struct MtfBufs {
   uint32_t* freq;     // [nb][258]
   uint8_t* alist;     // [nb][256] used byte values, ascending
   uint32_t *asz, *nheads, *npos;   // [nb]
+  int* segkeys;       // [nb][seg_stride][256] last-occurrence sort keys at every 32-chunk segment start
+  size_t seg_stride;
   size_t list_stride, a_stride, hstride;   // hstride: per-block stride of hpos/hsym/hrank (multiple of 16)
 };
 
@@ -21,6 +23,7 @@ struct MtfWork {
   uint32_t stride = 0;
   MtfBufs b{};
   static size_t list_stride_for(uint32_t stride) { return ((size_t)(stride + 255) / 256 + 1) * 256; }
+  static size_t seg_stride_for(uint32_t stride) { return ((size_t)stride + 8191) / 8192 + 1; }
   static size_t hstride_for(uint32_t stride) { return ((size_t)stride + 15) & ~(size_t)15; }
   static size_t a_stride_for(uint32_t stride) { return ((size_t)stride + 2 + 7) & ~(size_t)7; }
   static size_t bytes_needed(size_t max_blocks, uint32_t stride);

@@ -58,20 +58,57 @@ __global__ __launch_bounds__(1024) void mtf_heads(const uint8_t* __restrict__ U,
   if (threadIdx.x == 0) mb.nheads[blk] = carry;
 }
 
-// ---- C1: MTF list at the start of every chunk of 256 heads.  One workgroup per block, serial over chunks.
-__global__ __launch_bounds__(1024) void mtf_chunk_lists(uint32_t stride, MtfBufs mb) {
+// ---- C1: MTF list at the start of every chunk of 256 heads.
+// The list before a chunk = used symbols ordered by (last occurrence before the chunk, descending), never-seen
+// symbols after them in ascending byte order.  Three kernels so that the serial chain is 32 chunks long, not ~1000:
+//   mtf_seg_last  : per segment of 32 chunks, last head index of every byte value inside the segment
+//   mtf_seg_scan  : per block, running maximum over segments -> sort keys at every segment start
+//   mtf_chunk_lists: per segment, walk its 32 chunks: rank-by-counting over the <=256 keys, then fold the chunk in
+constexpr int MTF_SEG = 32;     // chunks per segment
+__global__ __launch_bounds__(256) void mtf_seg_last(MtfBufs mb) {
+  __shared__ int last[256];
+  const uint32_t blk = blockIdx.y, seg = blockIdx.x, H = mb.nheads[blk];
+  const uint32_t h0 = seg * MTF_SEG * MTF_CHUNK;
+  if (h0 >= H) return;
+  const uint32_t h1 = h0 + MTF_SEG * MTF_CHUNK < H ? h0 + MTF_SEG * MTF_CHUNK : H;
+  const uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
+  last[threadIdx.x] = -1;
+  __syncthreads();
+  for (uint32_t h = h0 + threadIdx.x; h < h1; h += 256) atomicMax(&last[hsym[h]], (int)h);
+  __syncthreads();
+  mb.segkeys[((size_t)blk * mb.seg_stride + seg) * 256 + threadIdx.x] = last[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void mtf_seg_scan(MtfBufs mb) {
+  __shared__ uint32_t used[256];
+  const uint32_t blk = blockIdx.x, H = mb.nheads[blk], asz = mb.asz[blk];
+  const uint32_t nseg = (H + MTF_SEG * MTF_CHUNK - 1) / (MTF_SEG * MTF_CHUNK);
+  used[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < asz) used[mb.alist[(size_t)blk * 256 + threadIdx.x]] = 1;
+  __syncthreads();
+  const int d = threadIdx.x;
+  int key = used[d] ? 255 - d : -1000;                 // never seen: ascending byte order behind every seen symbol
+  int* sk = mb.segkeys + (size_t)blk * mb.seg_stride * 256;
+  for (uint32_t sgi = 0; sgi < nseg; sgi++) {
+    const int l = sk[(size_t)sgi * 256 + d];            // last head index of d inside segment sgi (or -1)
+    sk[(size_t)sgi * 256 + d] = key;                    // becomes: key of d at the START of segment sgi
+    if (l >= 0) key = 256 + l;
+  }
+}
+__global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
   __shared__ int keys[256];
   __shared__ uint32_t part[4][256];
-  const uint32_t blk = blockIdx.x, H = mb.nheads[blk], asz = mb.asz[blk];
+  const uint32_t blk = blockIdx.y, seg = blockIdx.x, H = mb.nheads[blk];
+  const uint32_t nch = (H + MTF_CHUNK - 1) / MTF_CHUNK;
+  const uint32_t c0 = seg * MTF_SEG;
+  if (c0 >= nch) return;
+  const uint32_t c1 = c0 + MTF_SEG < nch ? c0 + MTF_SEG : nch;
   const uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
   uint8_t* lists = mb.lists + (size_t)blk * mb.list_stride;
-  if (threadIdx.x < 256) keys[threadIdx.x] = -1000;
+  if (threadIdx.x < 256) keys[threadIdx.x] = mb.segkeys[((size_t)blk * mb.seg_stride + seg) * 256 + threadIdx.x];
   __syncthreads();
-  if (threadIdx.x < asz) { const int d = mb.alist[(size_t)blk * 256 + threadIdx.x]; keys[d] = 255 - d; }
-  __syncthreads();
-  const uint32_t nch = (H + MTF_CHUNK - 1) / MTF_CHUNK;
   const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
-  for (uint32_t c = 0; c < nch; c++) {
+  for (uint32_t c = c0; c < c1; c++) {
     const int kd = keys[d];
     uint32_t cnt = 0;
 #pragma unroll 8
@@ -188,6 +225,7 @@ size_t MtfWork::bytes_needed(size_t max_blocks, uint32_t stride) {
   add(max_blocks * hs * 4); add(max_blocks * hs); add(max_blocks * hs); add(max_blocks * ls);
   add(max_blocks * as * 2); add(max_blocks * 258 * 4); add(max_blocks * 256);
   add(max_blocks * 4); add(max_blocks * 4); add(max_blocks * 4);
+  add(max_blocks * seg_stride_for(stride) * 256 * 4);
   return b + 4096;
 }
 int MtfWork::carve(Arena& a, size_t max_blocks_, uint32_t stride_) {
@@ -197,7 +235,9 @@ int MtfWork::carve(Arena& a, size_t max_blocks_, uint32_t stride_) {
   b.lists = a.take<uint8_t>(max_blocks * b.list_stride);
   b.A = a.take<uint16_t>(max_blocks * b.a_stride); b.freq = a.take<uint32_t>(max_blocks * 258); b.alist = a.take<uint8_t>(max_blocks * 256);
   b.asz = a.take<uint32_t>(max_blocks); b.nheads = a.take<uint32_t>(max_blocks); b.npos = a.take<uint32_t>(max_blocks);
-  return b.npos ? 0 : CJS_E_OUT_OF_MEMORY;
+  b.seg_stride = seg_stride_for(stride);
+  b.segkeys = a.take<int>(max_blocks * b.seg_stride * 256);
+  return b.segkeys ? 0 : CJS_E_OUT_OF_MEMORY;
 }
 
 int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const uint32_t* d_blen) {
@@ -205,7 +245,10 @@ int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const ui
   if (nb > w.max_blocks) return CJS_E_INVALID_ARG;
   const uint32_t max_chunks = (w.stride + MTF_CHUNK - 1) / MTF_CHUNK;
   hipLaunchKernelGGL(mtf_heads, dim3(nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b);
-  hipLaunchKernelGGL(mtf_chunk_lists, dim3(nb), dim3(1024), 0, s, w.stride, w.b);
+  const uint32_t max_segs = (max_chunks + MTF_SEG - 1) / MTF_SEG;
+  hipLaunchKernelGGL(mtf_seg_last, dim3(max_segs, nb), dim3(256), 0, s, w.b);
+  hipLaunchKernelGGL(mtf_seg_scan, dim3(nb), dim3(256), 0, s, w.b);
+  hipLaunchKernelGGL(mtf_chunk_lists, dim3(max_segs, nb), dim3(1024), 0, s, w.b);
   hipLaunchKernelGGL(mtf_replay, dim3((max_chunks + 255) / 256, nb), dim3(256), 0, s, w.stride, w.b);
   hipLaunchKernelGGL(mtf_emit, dim3(nb), dim3(1024), 0, s, w.stride, d_blen, w.b);
   CJS_HIP_TRY(hipGetLastError());

@@ -377,7 +377,7 @@ constexpr uint32_t CRC_SEG = 16384;   // bytes per workgroup: 256 threads x 64 b
 __global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict__ in, const RleBlock* __restrict__ blocks,
                                                        const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
                                                        uint32_t first, uint32_t* __restrict__ seg_crc) {
-  __shared__ uint32_t tab[256];
+  __shared__ uint32_t tab[4][256];     // slicing-by-4: tab[k][i] = CRC of byte i followed by k zero bytes
   __shared__ uint32_t part[256];
   const uint32_t k = first + blockIdx.y;
   if (k >= *nblocks_p) return;
@@ -387,13 +387,23 @@ __global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict
   {
     uint32_t c = (uint32_t)threadIdx.x << 24;
     for (int i = 0; i < 8; i++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : (c << 1);
-    tab[threadIdx.x] = c;
+    tab[0][threadIdx.x] = c;
   }
   __syncthreads();
+  for (int t = 1; t < 4; t++) {
+    const uint32_t p = tab[t - 1][threadIdx.x];
+    tab[t][threadIdx.x] = (p << 8) ^ tab[0][p >> 24];
+    __syncthreads();
+  }
   const uint64_t a = seg_start + (uint64_t)threadIdx.x * 64;
   uint64_t bend = a + 64; if (bend > bd.e) bend = bd.e;
   uint32_t crc = 0;
-  for (uint64_t p = a; p < bend; p++) crc = (crc << 8) ^ tab[((crc >> 24) ^ in[p]) & 0xff];
+  uint64_t p = a;
+  for (; p + 4 <= bend; p += 4) {
+    const uint32_t x = crc ^ (((uint32_t)in[p] << 24) | ((uint32_t)in[p + 1] << 16) | ((uint32_t)in[p + 2] << 8) | (uint32_t)in[p + 3]);
+    crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 0xff] ^ tab[1][(x >> 8) & 0xff] ^ tab[0][x & 0xff];
+  }
+  for (; p < bend; p++) crc = (crc << 8) ^ tab[0][((crc >> 24) ^ in[p]) & 0xff];
   part[threadIdx.x] = crc;
   __syncthreads();
   // tree combine: node (t, width w) = combine(left part[t], right part[t+w]) where right covers bytes
