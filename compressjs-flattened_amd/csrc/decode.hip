@@ -453,9 +453,13 @@ __global__ void ib_make_crc_ranges(const IbBlock* __restrict__ blocks, uint32_t 
 }  // namespace cjs
 
 // ---------------------------------------------------------------- host driver
-extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
-  if (!out || !out_n) return CJS_E_INVALID_ARG;
-  *out = nullptr; *out_n = 0;
+// mode 0: Bunzip.decode (:1769-1796); mode 1: Bunzip.table (:1823-1863) -> (bit position, size) per block, no bytes;
+// mode 2: Bunzip.decodeBlock (:1797-1818) -> the single block whose magic starts at `at_bit`
+static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, uint64_t at_bit, uint8_t** out, size_t* out_n,
+                       uint64_t* tab_pos, uint32_t* tab_size, long tab_cap, long* tab_n, const cjs_opts* opts) {
+  if (out) *out = nullptr;
+  if (out_n) *out_n = 0;
+  if (tab_n) *tab_n = 0;
   CJS_TRY(select_device(opts));
   // _start_bunzip (:1408-1427)
   if (n < 4 || in[0] != 'B' || in[1] != 'Z' || in[2] != 'h') return CJS_E_NOT_BZIP_DATA;
@@ -506,8 +510,17 @@ extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream
   };
   auto read_bits = [&](uint64_t bit, int k) -> uint64_t { uint64_t v = 0; for (int i = 0; i < k; i++) { const uint64_t b = bit + i; v = (v << 1) | ((b >> 3) < n ? (in[b >> 3] >> (7 - (b & 7))) & 1u : 0u); } return v; };
   std::vector<IbBlock> chain;
+  std::vector<uint64_t> chain_bits;
   uint64_t pos = 32; uint32_t stream_crc = 0;
-  for (;;) {
+  if (mode == 2) {                                               // reader.seekBit(pos); _get_next_block() (:1803-1805)
+    const long ci = find(at_bit);
+    if (ci < 0) rc = CJS_E_NOT_BZIP_DATA;
+    else if (cands[ci].kind == 0) {
+      const BlockOut& bo = bos[ci];
+      if (bo.err) rc = bo.err;
+      else { IbBlock ib; ib.cand = (uint32_t)ci; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc; chain.push_back(ib); chain_bits.push_back(at_bit); }
+    }
+  } else for (;;) {
     if ((pos + 7) / 8 >= n) break;                               // inputStream.eof() (:1777)
     const long ci = find(pos);
     if (ci < 0) { rc = CJS_E_NOT_BZIP_DATA; break; }             // h !== WHOLEPI (:1438)
@@ -517,14 +530,14 @@ extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream
       if (bo.err) { rc = bo.err; break; }
       stream_crc = bo.crc ^ ((stream_crc << 1) | (stream_crc >> 31));
       IbBlock ib; ib.cand = (uint32_t)ci; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
-      chain.push_back(ib);
+      chain.push_back(ib); chain_bits.push_back(pos);
       pos = bo.end_bit;
     } else {
       const uint32_t target = (uint32_t)read_bits(pos + 48, 32);
       pos += 80;
       if ((pos + 7) / 8 > n) pos = (uint64_t)n * 8;
       if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] end of stream at bit %llu: stream crc %08x stored %08x\n", (unsigned long long)pos - 80, stream_crc, target);
-      if (target != stream_crc) { rc = CJS_E_DATA_ERROR; break; }
+      if (mode == 0 && target != stream_crc) { rc = CJS_E_DATA_ERROR; break; }   // Bunzip.table ignores the stream crc (:1852)
       const uint64_t byte = (pos + 7) / 8;
       if (multistream && byte < n) {                            // _start_bunzip again, byte aligned (:1787-1792)
         if (byte + 4 > n || in[byte] != 'B' || in[byte + 1] != 'Z' || in[byte + 2] != 'h') { rc = CJS_E_NOT_BZIP_DATA; break; }
@@ -537,7 +550,7 @@ extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream
   }
   if (rc) { cleanup(); return rc; }
   const uint32_t nb = (uint32_t)chain.size();
-  if (nb == 0) { cleanup(); *out = (uint8_t*)malloc(1); *out_n = 0; return *out ? 0 : CJS_E_OUT_OF_MEMORY; }
+  if (nb == 0) { cleanup(); if (out) { *out = (uint8_t*)malloc(1); if (!*out) return CJS_E_OUT_OF_MEMORY; } return 0; }
 
   // ---- inverse BWT for the chain's blocks
   uint64_t M64 = 0;
@@ -596,21 +609,35 @@ extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream
   hipLaunchKernelGGL(ib_make_crc_ranges, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, d_ranges, d_nb);
   rc = crc_ranges(s, d_out, d_ranges, d_nb, nb, need_segs, d_seg, d_crc);
   std::vector<uint32_t> crcs(nb);
-  uint8_t* host = (uint8_t*)malloc(total ? total : 1);
-  if (!rc && !host) rc = CJS_E_OUT_OF_MEMORY;
+  uint8_t* host = out ? (uint8_t*)malloc(total ? total : 1) : nullptr;
+  if (!rc && out && !host) rc = CJS_E_OUT_OF_MEMORY;
   if (!rc && hipMemcpyAsync(crcs.data(), d_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc && total && hipMemcpyAsync(host, d_out, total, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && out && total && hipMemcpyAsync(host, d_out, total, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
   if (!rc) for (uint32_t k = 0; k < nb; k++) if (crcs[k] != chain[k].crc) {                                    // Bad block CRC (:1756-1761)
-    if (getenv("CJS_DEBUG")) {
-      fprintf(stderr, "[cjs dec] block %u: Bad block CRC (got %08x expected %08x) out_len %u:", k, crcs[k], chain[k].crc, chain[k].out_len);
-      for (uint32_t i = 0; i < chain[k].out_len && i < 40; i++) fprintf(stderr, " %02x", host[chain[k].out_off + i]);
-      fprintf(stderr, "\n");
-    }
+    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block %u: Bad block CRC (got %08x expected %08x) out_len %u\n", k, crcs[k], chain[k].crc, chain[k].out_len);
     rc = CJS_E_DATA_ERROR; break;
   }
   cleanup();
   if (rc) { free(host); return rc; }
-  *out = host; *out_n = (size_t)total;
+  if (tab_n) {
+    *tab_n = (long)nb;
+    for (uint32_t k = 0; k < nb && (long)k < tab_cap; k++) { tab_pos[k] = chain_bits[k]; tab_size[k] = chain[k].out_len; }
+  }
+  if (out) { *out = host; *out_n = (size_t)total; }
   return 0;
+}
+
+extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
+  if (!out || !out_n) return CJS_E_INVALID_ARG;
+  return bunzip_core(in, n, multistream, 0, 0, out, out_n, nullptr, nullptr, 0, nullptr, opts);
+}
+extern "C" int cjs_bzip2_decompress_block(const uint8_t* in, size_t n, uint64_t bitpos, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
+  if (!out || !out_n) return CJS_E_INVALID_ARG;
+  return bunzip_core(in, n, 0, 2, bitpos, out, out_n, nullptr, nullptr, 0, nullptr, opts);
+}
+extern "C" long cjs_bzip2_table(const uint8_t* in, size_t n, int multistream, uint64_t* bitpos, uint32_t* size, long cap, const cjs_opts* opts) {
+  long nbk = 0;
+  const int rc = bunzip_core(in, n, multistream, 1, 0, nullptr, nullptr, bitpos, size, cap, &nbk, opts);
+  return rc ? (long)rc : nbk;
 }

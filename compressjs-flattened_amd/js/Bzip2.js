@@ -38,5 +38,19 @@ Bzip2.decompressFile = function (inStream, outStream, multistream) {
   try { result = common.addon().bzip2Decompress(input.bytes, multistream ? 1 : 0); } catch (e) { rethrow(e); }
   return common.deliver(result, outStream);
 };
+// Bunzip.decodeBlock (J/Bzip2_joined_.js:1797-1818): the block whose magic starts at bit `pos`
+Bzip2.decompressBlock = function (inStream, pos, outStream) {
+  var input = common.coerceInput(inStream);
+  var result;
+  try { result = common.addon().bzip2DecompressBlock(input.bytes, pos); } catch (e) { rethrow(e); }
+  return common.deliver(result, outStream);
+};
+// Bunzip.table (:1823-1863): callback(position in bits, uncompressed size in bytes) once per block
+Bzip2.table = function (inStream, callback, multistream) {
+  var input = common.coerceInput(inStream);
+  var t;
+  try { t = common.addon().bzip2Table(input.bytes, multistream ? 1 : 0); } catch (e) { rethrow(e); }
+  for (var i = 0; i < t.length; i += 2) { callback(t[i], t[i + 1]); }
+};
 Bzip2.Err = Err;
 module.exports = Bzip2;

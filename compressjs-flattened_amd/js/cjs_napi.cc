@@ -19,6 +19,8 @@ struct Api {
   int (*bzip2_decompress)(const uint8_t*, size_t, int, uint8_t**, size_t*, const cjs_opts*) = nullptr;
   int (*bwtc_compress)(const uint8_t*, size_t, int, uint8_t**, size_t*, const cjs_opts*) = nullptr;
   int (*bwtc_decompress)(const uint8_t*, size_t, uint8_t**, size_t*, const cjs_opts*) = nullptr;
+  long (*bzip2_table)(const uint8_t*, size_t, int, uint64_t*, uint32_t*, long, const cjs_opts*) = nullptr;
+  int (*bzip2_decompress_block)(const uint8_t*, size_t, uint64_t, uint8_t**, size_t*, const cjs_opts*) = nullptr;
   void (*free_)(void*) = nullptr;
   const char* (*strerror_)(int) = nullptr;
   int (*device_count)(void) = nullptr;
@@ -42,6 +44,7 @@ bool load_api() {
 #define SYM(field, name) *(void**)(&api.field) = dlsym(api.handle, name); if (!api.field) { api.error = "missing symbol " name; api.handle = nullptr; return false; }
   SYM(bzip2_compress, "cjs_bzip2_compress") SYM(bzip2_decompress, "cjs_bzip2_decompress")
   SYM(bwtc_compress, "cjs_bwtc_compress") SYM(bwtc_decompress, "cjs_bwtc_decompress")
+  SYM(bzip2_table, "cjs_bzip2_table") SYM(bzip2_decompress_block, "cjs_bzip2_decompress_block")
   SYM(free_, "cjs_free") SYM(strerror_, "cjs_strerror") SYM(device_count, "cjs_device_count") SYM(version, "cjs_version")
 #undef SYM
   return true;
@@ -108,6 +111,44 @@ napi_value call_stream(napi_env env, napi_callback_info info) {
   return wrap_result(env, out, out_n);
 }
 
+// bzip2Table(input, multistream) -> Float64Array [pos0, size0, pos1, size1, ...]   (Bzip2.table)
+napi_value bzip2_table(napi_env env, napi_callback_info info) {
+  if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
+  size_t argc = 2; napi_value argv[2];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* p = nullptr; size_t n = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &p, &n)) { napi_throw_type_error(env, nullptr, "expected a Uint8Array or Buffer"); return nullptr; }
+  int32_t multi = 0;
+  if (argc >= 2) napi_get_value_int32(env, argv[1], &multi);
+  long cap = (long)(n / 32 + 64);
+  uint64_t* pos = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)cap);
+  uint32_t* size = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap);
+  static const uint8_t dummy = 0;
+  long nb = api.bzip2_table(p ? p : &dummy, n, multi, pos, size, cap, nullptr);
+  if (nb < 0) { free(pos); free(size); return throw_code(env, (int)nb); }
+  if (nb > cap) nb = cap;
+  napi_value ab, ta; void* dst;
+  napi_create_arraybuffer(env, sizeof(double) * 2 * (size_t)nb, &dst, &ab);
+  for (long i = 0; i < nb; i++) { ((double*)dst)[2 * i] = (double)pos[i]; ((double*)dst)[2 * i + 1] = (double)size[i]; }
+  free(pos); free(size);
+  napi_create_typedarray(env, napi_float64_array, 2 * (size_t)nb, ab, 0, &ta);
+  return ta;
+}
+// bzip2DecompressBlock(input, bitpos) -> Uint8Array   (Bzip2.decompressBlock)
+napi_value bzip2_block(napi_env env, napi_callback_info info) {
+  if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
+  size_t argc = 2; napi_value argv[2];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* p = nullptr; size_t n = 0;
+  if (argc < 2 || !get_bytes(env, argv[0], &p, &n)) { napi_throw_type_error(env, nullptr, "expected (Uint8Array, bit position)"); return nullptr; }
+  double bit = 0; napi_get_value_double(env, argv[1], &bit);
+  uint8_t* out = nullptr; size_t out_n = 0;
+  static const uint8_t dummy = 0;
+  const int rc = api.bzip2_decompress_block(p ? p : &dummy, n, (uint64_t)bit, &out, &out_n, nullptr);
+  if (rc != 0) return throw_code(env, rc);
+  return wrap_result(env, out, out_n);
+}
+
 napi_value device_count(napi_env env, napi_callback_info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
   napi_value v; napi_create_int32(env, api.device_count(), &v); return v;
@@ -123,6 +164,8 @@ napi_value init(napi_env env, napi_value exports) {
     {"bzip2Decompress", nullptr, call_stream<1>, nullptr, nullptr, nullptr, napi_default, nullptr},
     {"bwtcCompress", nullptr, call_stream<2>, nullptr, nullptr, nullptr, napi_default, nullptr},
     {"bwtcDecompress", nullptr, call_stream<3>, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"bzip2Table", nullptr, bzip2_table, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"bzip2DecompressBlock", nullptr, bzip2_block, nullptr, nullptr, nullptr, napi_default, nullptr},
     {"deviceCount", nullptr, device_count, nullptr, nullptr, nullptr, napi_default, nullptr},
     {"version", nullptr, version, nullptr, nullptr, nullptr, napi_default, nullptr},
   };

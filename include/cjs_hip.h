@@ -66,6 +66,11 @@ int cjs_bzip2_compress(const uint8_t *in, size_t n, int level, uint8_t **out, si
 int cjs_bzip2_decompress(const uint8_t *in, size_t n, int multistream, uint8_t **out, size_t *out_n, const cjs_opts *opts);
 int cjs_bwtc_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n, const cjs_opts *opts);
 int cjs_bwtc_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, const cjs_opts *opts);
+/* Bzip2.table (J/Bzip2_joined_.js:1823-1863): fills (bit position, uncompressed size) of up to `cap` blocks,
+ * returns the number of blocks or a negative code.  Bzip2.decompressBlock (:1797-1818): the single block
+ * whose 48-bit magic starts at bit `bitpos`. */
+long cjs_bzip2_table(const uint8_t *in, size_t n, int multistream, uint64_t *bitpos, uint32_t *size, long cap, const cjs_opts *opts);
+int cjs_bzip2_decompress_block(const uint8_t *in, size_t n, uint64_t bitpos, uint8_t **out, size_t *out_n, const cjs_opts *opts);
 void cjs_free(void *p);
 const char *cjs_strerror(int code);
 int cjs_device_count(void);

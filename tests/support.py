@@ -203,6 +203,8 @@ class HipLib(_StreamLib):
             "cjs_free": [V],
             "cjs_strerror": [I],
             "cjs_device_count": [],
+            "cjs_bzip2_decompress_block": [u8p, S, ctypes.c_uint64, PP, PS, V],
+            "cjs_bzip2_table": [u8p, S, I, V, V, ctypes.c_long, V],
             "cjs_stage_bwt": [V, S, I, I, V, V, V],
             "cjs_stage_rle1": [V, S, I, V, S, V, V, V, ctypes.c_long, ctypes.POINTER(ctypes.c_long), V],
             "cjs_stage_mtf": [V, V, S, I, V, V, V, V, V],
@@ -219,6 +221,8 @@ class HipLib(_StreamLib):
         L.cjs_strerror.restype = ctypes.c_char_p
         L.cjs_version.restype = ctypes.c_char_p
         L.cjs_free.restype = None
+        if hasattr(L, "cjs_bzip2_table"):
+            L.cjs_bzip2_table.restype = ctypes.c_long
 
     def _free(self, p):
         self.L.cjs_free(p)
@@ -234,6 +238,18 @@ class HipLib(_StreamLib):
 
     def bwtc_decompress(self, data):
         return self._call_stream(self.L.cjs_bwtc_decompress, self._free, data, tail=(None,))
+
+    def bzip2_decompress_block(self, data, bitpos):
+        return self._call_stream(self.L.cjs_bzip2_decompress_block, self._free, data, ctypes.c_uint64(bitpos), tail=(None,))
+
+    def bzip2_table(self, data, multistream=0, cap=100000):
+        data = as_u8(data)
+        pos = np.zeros(cap, dtype=np.uint64)
+        size = np.zeros(cap, dtype=np.uint32)
+        n = self.L.cjs_bzip2_table(data.ctypes.data_as(u8p), data.size, multistream, pos.ctypes.data, size.ctypes.data, cap, None)
+        if n < 0:
+            return n, None
+        return 0, list(zip(pos[:n].tolist(), size[:n].tolist()))
 
     def stage_bwt(self, data, block_len, cyclic):
         data = as_u8(data)

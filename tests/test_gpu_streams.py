@@ -152,3 +152,26 @@ def test_bzip2_decompress_10m(hip, oracle):
     assert rc == 0
     rc, out = hip.bzip2_decompress(comp)
     assert rc == 0 and np.array_equal(out, data)
+
+
+@pytest.mark.parametrize("name", ["sample0", "sample1", "sample2", "sample3", "sample4"])
+def test_bzip2_table_goldens(hip, name):
+    # NPM/test/bzip2-table.js
+    comp = np.fromfile(os.path.join(recipes.DATA, name + ".bz2"), dtype=np.uint8)
+    rc, table = hip.bzip2_table(comp)
+    assert rc == 0
+    text = "".join("%d\t%d\n" % (p, s) for p, s in table)
+    assert text == open(os.path.join(recipes.DATA, name + ".bzt")).read()
+
+
+@pytest.mark.parametrize("name,bitpos", [("sample0", 32), ("sample2", 544888), ("sample4", 32), ("sample4", 1596228), ("sample4", 2342106)])
+def test_bzip2_decompress_block_goldens(hip, oracle, name, bitpos):
+    # NPM/test/bzip2-block.js
+    comp = np.fromfile(os.path.join(recipes.DATA, name + ".bz2"), dtype=np.uint8)
+    rc, out = hip.bzip2_decompress_block(comp, bitpos)
+    assert rc == 0
+    if name == "sample0":
+        assert out.tobytes() == b"This is a test\n"
+    else:
+        ref = np.fromfile(os.path.join(recipes.DATA, "%s.%d" % (name, bitpos)), dtype=np.uint8)
+        assert np.array_equal(out, ref)
