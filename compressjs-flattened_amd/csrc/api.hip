@@ -121,5 +121,3 @@ extern "C" int cjs_stage_rle1(const uint8_t* in, size_t n, int level, uint8_t* b
   return rc;
 }
 
-// ---- not built yet in this round: fail loudly, never fall back to a CPU path
-extern "C" int cjs_bwtc_decompress(const uint8_t*, size_t, uint8_t**, size_t*, const cjs_opts*) { return CJS_E_UNSUPPORTED; }

@@ -15,7 +15,10 @@
 #include <string.h>
 #include <vector>
 
-namespace cjs { int select_device(const cjs_opts* opts); }
+namespace cjs {
+int select_device(const cjs_opts* opts);
+int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32_t nb, const uint32_t* lens, const uint32_t* pidx, uint8_t* d_out);
+}
 using namespace cjs;
 
 namespace cjs {
@@ -314,5 +317,212 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
   if (!host) return CJS_E_OUT_OF_MEMORY;
   memcpy(host, o.data(), o.size());
   *out = host; *out_n = o.size();
+  return 0;
+}
+
+
+// ---------------------------------------------------------------- BWTC.decompressFile (J/BWTC_joined_.js:1827-1920)
+// Range decoding and the adaptive model are one serial chain over the whole file (every decoded symbol feeds the
+// model that decodes the next one), so that part runs on one host thread; the inverse BWT of all blocks
+// (BWT.unbwtransform, n dependent gathers per block in the reference) runs on the GPU (decode.hip).
+namespace {
+
+struct HostDecoder {                                    // RangeCoder decode side (:159-238)
+  const uint8_t* in; size_t n, pos;
+  uint32_t low = 0, range = 0, help = 0; int32_t buffer = 0;
+  int32_t read_byte() { return pos < n ? (int32_t)in[pos++] : -1; }
+  void start() { buffer = read_byte(); low = (uint32_t)buffer >> 1; range = 1u << 7; }          // decodeStart(skipInitialRead)
+  inline void normalize() {
+    while (range <= 0x00800000u) {
+      low = (low << 8) | (((uint32_t)buffer << 7) & 0xFF);
+      buffer = read_byte();
+      low |= (uint32_t)buffer >> 1;
+      range <<= 8;
+    }
+  }
+  inline uint32_t cul_freq(uint32_t tot) { normalize(); help = range / tot; const uint32_t t = help ? low / help : 0; return t >= tot ? tot - 1 : t; }
+  inline uint32_t cul_shift(int sh) { normalize(); help = range >> sh; const uint32_t t = help ? low / help : 0; return (t >> sh) ? (1u << sh) - 1 : t; }
+  inline void update(uint32_t sy, uint32_t lt, uint32_t tot) { const uint32_t tmp = help * lt; low -= tmp; if (lt + sy < tot) range = help * sy; else range -= tmp; }
+  uint32_t bit() { const uint32_t t = cul_shift(1); update(1, t, 2); return t; }
+  bool overrun() const { return pos >= n + 8; }
+};
+uint32_t nomodel_dec(HostDecoder& d, int bits) { uint32_t r = 0; for (int i = bits - 1; i >= 0; i--) { r <<= 1; if (d.bit()) r++; } return r; }
+uint32_t logdist_dec(HostDecoder& d, int block_size) {                                          // :1254-1261
+  const int lgbits = fls32((uint32_t)(1 + fls32((uint32_t)block_size - 1)) - 1);
+  const uint32_t lg = nomodel_dec(d, lgbits);
+  if (lg < 2) return lg;
+  return (1u << (lg - 1)) + nomodel_dec(d, (int)lg - 1);
+}
+
+struct FenDec {                                         // FenwickModel decode side (:1572-1661)
+  HostDecoder& d; int num_syms; std::vector<uint32_t> tree;
+  FenDec(HostDecoder& dd, int size) : d(dd), num_syms(size + 1), tree((size_t)(size + 1) * 2, 0) {
+    int i; for (i = 0; i < size; i++) tree[num_syms + i] = 1u;
+    tree[num_syms + i] = 0x100u << 16; sum();
+  }
+  void sum() { for (int i = num_syms - 1; i > 0; i--) tree[i] = tree[2 * i] + tree[2 * i + 1]; }
+  void rescale() {
+    int i; bool no_escape = true; uint32_t prob;
+    for (i = 0; i < num_syms - 1; i++) {
+      prob = tree[num_syms + i];
+      if (prob & 0xFFFFu) { no_escape = false; continue; }
+      prob = (prob & 0xFFFEFFFEu) >> 1;
+      if (prob == 0) { prob = 1u; no_escape = false; }
+      tree[num_syms + i] = prob;
+    }
+    prob = tree[num_syms + i]; prob = (prob & 0xFFFEFFFEu) >> 1;
+    if (no_escape) prob = 0; else if (prob == 0) prob = 1u << 16;
+    tree[num_syms + i] = prob; sum();
+  }
+  int decode1(bool esc) {
+    uint32_t mask = 0xFFFF0000u; int shift = 16; uint32_t upd = 0x100u << 16;
+    if (esc) { mask = 0xFFFFu; upd -= 1u; shift = 0; }
+    const uint32_t tot = (tree[1] & mask) >> shift;
+    if (tot == 0) return -1;
+    const uint32_t prob = d.cul_freq(tot);
+    int i = 1; uint32_t lt = 0;
+    while (i < num_syms) {
+      tree[i] += upd;
+      const uint32_t left = (tree[2 * i] & mask) >> shift;
+      i *= 2;
+      if (prob - lt >= left) { lt += left; i++; }
+    }
+    const int symbol = i - num_syms;
+    const uint32_t sy = (tree[i] & mask) >> shift;
+    tree[i] += upd;
+    d.update(sy, lt, tot);
+    if (symbol == num_syms - 1 && (tree[1] & 0xFFFFu) == 1u) { upd = 0u - tree[i]; while (i >= 1) { tree[i] += upd; i >>= 1; } }
+    if ((tree[1] >> 16) >= 0xFF00u) rescale();
+    return symbol;
+  }
+  int decode() { int s = decode1(false); if (s == num_syms - 1) s = decode1(true); return s; }
+};
+
+struct DsmDec {                                         // DefSumModel decode side (:1327-1459)
+  HostDecoder& d; int ns; uint16_t prob[304], esc[304], upd[304], p2s[256], e2s[304]; int ucount = 0, uthresh = 128;
+  DsmDec(HostDecoder& dd, int size) : d(dd), ns(size) {
+    memset(prob, 0, sizeof prob); memset(esc, 0, sizeof esc); memset(upd, 0, sizeof upd);
+    prob[ns + 1] = 256;
+    for (int i = 0; i <= ns; i++) esc[i] = (uint16_t)i;
+    for (int i = 0; i < 256; i++) p2s[i] = (uint16_t)ns;
+    for (int i = 0; i < 304; i++) e2s[i] = (uint16_t)(i < ns ? i : 0);
+  }
+  void update(int symbol) {
+    if (symbol == ns) { if (upd[symbol] >= 40) return; if (ucount >= uthresh - 1) return; }
+    upd[symbol]++; ucount++;
+    if (ucount < uthresh) return;
+    int cum = 0, cum_esc = 0, odd = 0, i;
+    esc[0] = 0; prob[0] = 0;
+    for (i = 0; i < ns + 1; i++) {
+      const int np = ((prob[i + 1] - prob[i]) >> 1) + upd[i];
+      prob[i] = (uint16_t)cum; esc[i] = (uint16_t)cum_esc;
+      if (np) { cum += np; odd += np & 1; } else cum_esc++;
+    }
+    prob[i] = (uint16_t)cum;
+    uthresh = 256 - (cum - odd) / 2;
+    for (i = 0; i < ns + 1; i++) upd[i] = 0;
+    upd[ns] = 1; ucount = 1;
+    int j = 0, k = 0;
+    for (i = 0; i < ns + 1; i++) {
+      for (; j < prob[i + 1]; j++) p2s[j] = (uint16_t)i;
+      const int el = i + 1 <= ns ? esc[i + 1] : 0;       // escape[] has ns+1 entries in the reference
+      for (; k < el; k++) e2s[k] = (uint16_t)i;
+    }
+  }
+  int decode() {
+    uint32_t p = d.cul_shift(8);
+    int symbol = p2s[p];
+    uint32_t lt = prob[symbol], sy = (uint32_t)prob[symbol + 1] - lt;
+    d.update(sy, lt, 256); update(symbol);
+    if (symbol != ns) return symbol;
+    const uint32_t tot = esc[ns];
+    if (tot == 0) return -1;
+    p = d.cul_freq(tot);
+    symbol = e2s[p];
+    lt = esc[symbol]; sy = (uint32_t)esc[symbol + 1] - lt;
+    d.update(sy, lt, tot); update(symbol);
+    return symbol;
+  }
+};
+
+}  // namespace
+
+extern "C" int cjs_bwtc_decompress(const uint8_t* in, size_t n, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
+  if (!out || !out_n) return CJS_E_INVALID_ARG;
+  *out = nullptr; *out_n = 0;
+  CJS_TRY(select_device(opts));
+  if (n < 4 || in[0] != 'b' || in[1] != 'w' || in[2] != 't' || in[3] != 'c') return CJS_E_BAD_MAGIC;     // :559-565
+  size_t p = 4;
+  for (;;) { if (p >= n) return CJS_E_DATA_ERROR; if (in[p++] & 0x80) break; }                          // readUnsignedNumber :621-633
+  HostDecoder d{in, n, p};
+  d.start();
+  const uint32_t lv = d.cul_shift(8); d.update(1, lv, 256);                                            // decodeByte :1830
+  if (lv < 1 || lv > 9) return CJS_E_DATA_ERROR;
+  const bool fast = lv <= 5;
+  const uint32_t bs = lv * 100000u;
+  std::vector<uint8_t> T;                                // BWT columns of all blocks, stride bs
+  std::vector<uint32_t> lens, pidx;
+  for (;;) {
+    const uint32_t ind = d.cul_freq(3); d.update(1, ind, 3);
+    uint32_t length;
+    if (ind == 0) length = bs;
+    else if (ind == 1) { length = logdist_dec(d, (int)bs); if (length > bs) return CJS_E_DATA_ERROR; }
+    else break;
+    const uint32_t pi = logdist_dec(d, (int)bs);
+    uint16_t tree[512]; memset(tree, 0, sizeof tree); tree[0] = 1;                                     // use-tree :1859-1874
+    for (int i = 1; i < 512; i++) {
+      const int parent = i >> 1, full = 1 << (9 - fls32((uint32_t)i));
+      if (tree[parent] == 0 || tree[parent] == full * 2) tree[i] = tree[parent] >> 1;
+      else if (i >= 256) tree[i] = (uint16_t)d.bit();
+      else { const uint32_t v = d.cul_freq(3); d.update(1, v, 3); tree[i] = (uint16_t)(v == 2 ? (uint32_t)full : v); }
+    }
+    uint8_t M[256]; int asz = 0;
+    for (int i = 0; i < 256; i++) if (tree[256 + i]) M[asz++] = (uint8_t)i;
+    const size_t base = T.size();
+    T.resize(base + bs);
+    uint8_t* b = T.data() + base;
+    FenDec* fm = fast ? nullptr : new FenDec(d, asz + 1);
+    DsmDec* dm = fast ? new DsmDec(d, asz + 1) : nullptr;
+    uint64_t val = 1; uint32_t i = 0; bool bad = false;
+    while (i < length) {                                                                               // :1888-1903
+      const int c = fast ? dm->decode() : fm->decode();
+      if (c < 0 || d.overrun()) { bad = true; break; }
+      if (c == 0) { if (i + val > length) { bad = true; break; } for (uint64_t j = 0; j < val; j++) b[i++] = 0; val *= 2; }
+      else if (c == 1) { if (i + 2 * val > length) { bad = true; break; } for (uint64_t j = 0; j < 2 * val; j++) b[i++] = 0; val *= 2; }
+      else { val = 1; if (c - 1 >= asz) { bad = true; break; } b[i++] = (uint8_t)(c - 1); }
+    }
+    delete fm; delete dm;
+    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwtc dec] block %zu: length %u pidx %u asz %d decoded %u bad %d inpos %zu/%zu\n", lens.size(), length, pi, asz, i, (int)bad, d.pos, n);
+    if (bad) return CJS_E_DATA_ERROR;
+    for (i = 0; i < length; i++) {                                                                     // MTF decode :1905-1913
+      int j = b[i]; const uint8_t c = M[j];
+      b[i] = c;
+      for (; j > 0; j--) M[j] = M[j - 1];
+      M[0] = c;
+    }
+    if (pi > length) return CJS_E_DATA_ERROR;
+    lens.push_back(length); pidx.push_back(pi);
+  }
+  const uint32_t nb = (uint32_t)lens.size();
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nb; k++) total += lens[k];
+  uint8_t* host = (uint8_t*)malloc(total ? total : 1);
+  if (!host) return CJS_E_OUT_OF_MEMORY;
+  if (nb) {
+    // n <= 1 blocks: unbwtransform copies (:1149-1152); handled by the same kernels (a 1-element chain)
+    uint8_t *d_T = nullptr, *d_out = nullptr; hipStream_t s = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&d_T, T.size() + 64) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
+    if (!rc && hipMalloc((void**)&d_out, total + 64) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
+    if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemcpyAsync(d_T, T.data(), T.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc) rc = ibwt_sentinel_run(s, d_T, bs, nb, lens.data(), pidx.data(), d_out);
+    if (!rc && total && hipMemcpy(host, d_out, total, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (s) (void)hipStreamDestroy(s);
+    if (d_T) (void)hipFree(d_T);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) { free(host); return rc; }
+  }
+  *out = host; *out_n = (size_t)total;
   return 0;
 }

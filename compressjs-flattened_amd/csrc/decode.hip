@@ -283,22 +283,33 @@ __global__ __launch_bounds__(256) void ib_pack(const uint8_t* __restrict__ tt_al
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < b.count; j += gridDim.x * 256)
     dbuf[b.off + j] = (val[b.off + j] << 8) | tt_all[(size_t)b.cand * dbuf_size + j];
 }
+// sentinel variant (BWT.unbwtransform, J/BWTC_joined_.js:1147-1168): next(t) = LF[t] + C[T[t]] (+1 below pidx) = the stable
+// sorted position of element t; slot t holds (next(t) << 8) | T[t].  b.orig carries pidx.
+__global__ __launch_bounds__(256) void ib_pack_sentinel(const uint8_t* __restrict__ tt_all, uint32_t tt_stride, const IbBlock* __restrict__ blocks,
+                                                        const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf) {
+  const IbBlock b = blocks[blockIdx.y];
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < b.count; j += gridDim.x * 256) {
+    const uint32_t t = val[b.off + j];
+    dbuf[b.off + t] = ((j + (j < b.orig ? 1u : 0u)) << 8) | tt_all[(size_t)b.cand * tt_stride + t];
+  }
+}
 // splitters: slot j with j % SPL == 0, plus the start slot.  Walk until the next splitter.
 __device__ __forceinline__ bool is_split(uint32_t j, uint32_t start) { return (j % SPL) == 0 || j == start; }
+constexpr uint32_t SPL_END = 0xFFFFFFFEu;   // the chain left the block (sentinel variant: the row of the implicit end marker)
 __global__ __launch_bounds__(256) void ib_walk1(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t spl_stride,
-                                                uint32_t* __restrict__ spl_next, uint32_t* __restrict__ spl_steps) {
+                                                uint32_t* __restrict__ spl_next, uint32_t* __restrict__ spl_steps, int sentinel) {
   const IbBlock b = blocks[blockIdx.y];
   const uint32_t* d = dbuf + b.off;
-  const uint32_t start = d[b.orig] >> 8;                       // first slot visited by the loop (:1698-1700)
+  const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;       // first slot visited by the loop (:1698-1700)
   const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;         // regular splitters + one slot for `start`
   for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < nspl; sidx += gridDim.x * 256) {
     uint32_t pos;
     if (sidx == nspl - 1) { pos = start; if ((start % SPL) == 0) { spl_steps[(size_t)blockIdx.y * spl_stride + sidx] = 0; spl_next[(size_t)blockIdx.y * spl_stride + sidx] = start / SPL; continue; } }
     else pos = sidx * SPL;
     uint32_t steps = 0, cur = pos;
-    do { cur = d[cur] >> 8; steps++; } while (!is_split(cur, start) && steps < b.count);
+    do { cur = d[cur] >> 8; steps++; } while (cur < b.count && !is_split(cur, start) && steps < b.count);
     spl_steps[(size_t)blockIdx.y * spl_stride + sidx] = steps;
-    spl_next[(size_t)blockIdx.y * spl_stride + sidx] = (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
+    spl_next[(size_t)blockIdx.y * spl_stride + sidx] = cur >= b.count ? SPL_END : (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
   }
 }
 // rank the splitter chain from `start`: spl_rank[s] = number of output positions before splitter s's segment
@@ -316,6 +327,7 @@ __global__ void ib_rank(const IbBlock* __restrict__ blocks, uint32_t nblocks, ui
   for (uint32_t guard = 0; guard <= nspl + 1 && done < b.count; guard++) {
     if (rk[cur] != 0xFFFFFFFFu && st[cur] != 0) break;           // back on a visited splitter: the permutation has a short cycle
     rk[cur] = done; done += st[cur]; cur = nx[cur];
+    if (cur == SPL_END) break;
   }
   // done < count: the LF permutation has a short cycle (periodic block, e.g. "abab"): the reference keeps walking
   // round it for `count` steps (:1732), i.e. the byte sequence is periodic with period `done`
@@ -331,11 +343,11 @@ __global__ __launch_bounds__(256) void ib_periodic_fill(const IbBlock* __restric
 // second walk: write the pre-RLE1 byte sequence w[0..n) of each block (w[r] = byte of the (r+1)-th visited slot)
 __global__ __launch_bounds__(256) void ib_walk2(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t spl_stride,
                                                 const uint32_t* __restrict__ spl_rank, const uint32_t* __restrict__ spl_steps,
-                                                uint8_t* __restrict__ wbuf) {
+                                                uint8_t* __restrict__ wbuf, int sentinel) {
   const IbBlock b = blocks[blockIdx.y];
   const uint32_t* d = dbuf + b.off;
   uint8_t* w = wbuf + b.off;
-  const uint32_t start = d[b.orig] >> 8;
+  const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;
   const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;
   for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < nspl; sidx += gridDim.x * 256) {
     const uint32_t rank = spl_rank[(size_t)blockIdx.y * spl_stride + sidx], steps = spl_steps[(size_t)blockIdx.y * spl_stride + sidx];
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(256) void ib_walk2(const uint32_t* __restrict__ dbu
     // visiting order: position `rank` of the walk is slot `cur`; the loop outputs the byte of every visited slot (:1735-1736)
     for (uint32_t q = 0; q < steps && rank + q < b.count; q++) {
       const uint32_t e = d[cur];
-      w[rank + q] = (uint8_t)(e & 0xFF);
+      w[sentinel ? b.count - 1 - (rank + q) : rank + q] = (uint8_t)(e & 0xFF);     // unbwtransform fills U from the end (BWTC:1161)
       cur = e >> 8;
     }
   }
@@ -450,6 +462,60 @@ __global__ void ib_make_crc_ranges(const IbBlock* __restrict__ blocks, uint32_t 
   ranges[k] = r;
 }
 
+}  // namespace cjs
+
+// ---------------------------------------------------------------- inverse sentinel BWT of a batch (used by BWTC.decompressFile)
+namespace cjs {
+int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32_t nb, const uint32_t* lens, const uint32_t* pidx, uint8_t* d_out) {
+  if (!nb) return 0;
+  std::vector<IbBlock> chain(nb);
+  uint64_t M64 = 0;
+  for (uint32_t k = 0; k < nb; k++) {
+    IbBlock& b = chain[k];
+    b.cand = k; b.count = lens[k]; b.orig = pidx[k]; b.off = (uint32_t)M64; b.out_off = M64; b.out_len = lens[k]; b.crc = 0;
+    M64 += lens[k];
+  }
+  if (M64 >= 0xFFFFF000ull) return CJS_E_UNSUPPORTED;
+  const uint32_t M = (uint32_t)M64;
+  std::vector<void*> to_free;
+  auto dmalloc = [&](void** p, size_t bytes) { if (hipMalloc(p, bytes ? bytes : 4) != hipSuccess) return CJS_E_OUT_OF_MEMORY; to_free.push_back(*p); return 0; };
+  auto cleanup = [&]() { for (void* p : to_free) (void)hipFree(p); };
+  IbBlock* d_blocks = nullptr; uint32_t *d_key0 = nullptr, *d_key1 = nullptr, *d_val0 = nullptr, *d_val1 = nullptr;
+  uint32_t *d_snext = nullptr, *d_ssteps = nullptr, *d_srank = nullptr; int32_t* d_err = nullptr;
+  const uint32_t spl_stride = stride / SPL + 4;
+  BwtWork sw;
+  int rc = dmalloc((void**)&d_blocks, sizeof(IbBlock) * nb);
+  if (!rc) rc = dmalloc((void**)&d_key0, 4 * (size_t)M + 64); if (!rc) rc = dmalloc((void**)&d_key1, 4 * (size_t)M + 64);
+  if (!rc) rc = dmalloc((void**)&d_val0, 4 * (size_t)M + 64); if (!rc) rc = dmalloc((void**)&d_val1, 4 * (size_t)M + 64);
+  if (!rc) rc = dmalloc((void**)&d_snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_ssteps, 4 * (size_t)nb * spl_stride);
+  if (!rc) rc = dmalloc((void**)&d_srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_err, 4 * (size_t)nb);
+  const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
+  if (!rc) rc = dmalloc((void**)&sw.hist, 256 * T * 4); if (!rc) rc = dmalloc((void**)&sw.bintot, 256 * 4);
+  if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  if (rc) { cleanup(); return rc; }
+  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_T, stride, d_blocks, d_key0, d_val0);
+  int cur = 0;
+  int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
+  rc = radix_passes_public<uint32_t>(s, sw, d_key0, d_val0, d_key1, d_val1, cur, M, 0, kbits);
+  if (rc) { cleanup(); return rc; }
+  uint32_t* sval = cur ? d_val1 : d_val0;
+  uint32_t* d_dbuf = cur ? d_key0 : d_key1;
+  hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_T, stride, d_blocks, sval, d_dbuf);
+  hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 1);
+  hipLaunchKernelGGL(ib_rank, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
+  hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_out, 1);
+  std::vector<int32_t> errs(nb);
+  if (hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+  cleanup();
+  if (rc) return rc;
+  // The chain visits n distinct rows and then re-enters at row pidx (the step the reference computes last and never
+  // uses, BWTC:1163-1165), so the last segment may overshoot; a chain that closes before n rows is corrupt input.
+  for (uint32_t k = 0; k < nb; k++) if ((uint32_t)errs[k] < lens[k]) {
+    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs ibwt] block %u: chain covers %d of %u\n", k, errs[k], lens[k]);
+    return CJS_E_DATA_ERROR;
+  }
+  return 0;
+}
 }  // namespace cjs
 
 // ---------------------------------------------------------------- host driver
@@ -582,9 +648,9 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   d_dbuf = cur ? d_key0 : d_key1;                                // the buffer the sort is not sitting in
   (void)skey;
   hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, d_tt, dbuf_size, d_blocks, sval, d_dbuf);
-  hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps);
+  hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 0);
   hipLaunchKernelGGL(ib_rank, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
-  hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_w);
+  hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_w, 0);
   hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, d_blocks, d_err, d_w);
   hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_w, d_blocks, (uint8_t*)nullptr, 0);
   std::vector<int32_t> errs(nb);

@@ -175,3 +175,17 @@ def test_bzip2_decompress_block_goldens(hip, oracle, name, bitpos):
     else:
         ref = np.fromfile(os.path.join(recipes.DATA, "%s.%d" % (name, bitpos)), dtype=np.uint8)
         assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("case", [c for c in _bwtc_cases() if c["level"] in (1, 9)], ids=lambda c: "%s-%d" % (c["name"], c["level"]))
+def test_bwtc_decompress_round_trip(hip, oracle, case):
+    data = recipes.build(case["recipe"])
+    rc, comp = oracle.bwtc_compress(data, case["level"])       # == the reference's stream (pinned by the goldens)
+    assert rc == 0 and support.sha256(comp) == case["out_sha256"]
+    rc, out = hip.bwtc_decompress(comp)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == data.size and np.array_equal(out, data)
+
+
+def test_bwtc_errors(hip):
+    assert hip.bwtc_decompress(b"nope, not bwtc")[0] == -21
