@@ -19,7 +19,7 @@ hip: $(PKG)/libcjs_hip.so
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(PKG)/libcjs_hip.so: $(HIP_OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS) -lpthread
 
 oracle: oracle/libcjs_oracle.so
 oracle/libcjs_oracle.so: oracle/cjs_oracle.c oracle/cjs_oracle.h

@@ -7,7 +7,9 @@
 #include "huff.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace cjs;
@@ -174,11 +176,93 @@ extern "C" int cjs_bzip2_compress_device_range(cjs_ctx* c, const uint8_t* d_in, 
   return compress_core(c, d_in, n, level, first_block, count, false, d_out, out_cap, out_bits, block_crcs, crc_cap, total_blocks, stats);
 }
 
+// One shard of a multi-GPU job: its own device, context and stream; compresses blocks [first, first+count)
+// of the (replicated) input and brings its bare bit string back to the host.
+struct Shard {
+  int device = 0, rc = 0;
+  long first = 0, count = 0, total_blocks = 0;
+  uint64_t bits = 0;
+  std::vector<uint8_t> bytes;
+  std::vector<uint32_t> crcs;      // all block crcs of the stream; only [first, first+count) are valid
+};
+static void run_shard(Shard* sh, const uint8_t* in, size_t n, int level, long max_range_blocks) {
+  cjs_ctx* c = nullptr;
+  if (hipSetDevice(sh->device) != hipSuccess) { sh->rc = CJS_E_HIP; return; }
+  sh->rc = cjs_ctx_create_sharded(&c, sh->device, n, max_range_blocks, level);
+  if (sh->rc) return;
+  const size_t per = (size_t)max_range_blocks * ((size_t)level * 100000);
+  const size_t out_cap = (per + per / 4 + 65536 + 3) & ~(size_t)3;
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  if (hipMalloc((void**)&d_in, n ? n : 4) != hipSuccess) sh->rc = CJS_E_OUT_OF_MEMORY;
+  if (!sh->rc && hipMalloc((void**)&d_out, out_cap) != hipSuccess) sh->rc = CJS_E_OUT_OF_MEMORY;
+  if (!sh->rc && n && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) sh->rc = CJS_E_HIP;
+  sh->crcs.assign((size_t)Rle1Work::max_blocks_for(n, c->cap) + 1, 0u);
+  if (!sh->rc) sh->rc = cjs_bzip2_compress_device_range(c, d_in, n, level, sh->first, sh->count, d_out, out_cap, &sh->bits, sh->crcs.data(),
+                                                        (long)sh->crcs.size(), &sh->total_blocks, nullptr);
+  if (!sh->rc) {
+    sh->bytes.resize((size_t)((sh->bits + 7) / 8) + 8);
+    if (hipMemcpy(sh->bytes.data(), d_out, sh->bytes.size(), hipMemcpyDeviceToHost) != hipSuccess) sh->rc = CJS_E_HIP;
+  }
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  cjs_ctx_destroy(c);
+}
+
+// Multi-GPU host path: blocks are dealt in contiguous ranges to per-GPU worker threads; the only
+// cross-shard data are (bit length, block CRCs).  The host funnel-shifts the bit strings into one stream.
+static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshards, uint8_t** out, size_t* out_n) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CJS_E_NO_DEVICE;
+  const uint32_t cap = (uint32_t)level * 100000u - 19u;
+  // the exact block count needs the boundary pass; the ranges are planned from its upper bound and trimmed by each shard
+  Shard probe; probe.device = 0; probe.first = 0; probe.count = 0;
+  run_shard(&probe, in, n, level, 1);
+  if (probe.rc) return probe.rc;
+  const long total = probe.total_blocks;
+  const long share = total ? (total + nshards - 1) / nshards : 0;
+  std::vector<Shard> sh(nshards);
+  std::vector<std::thread> th;
+  for (uint32_t i = 0; i < nshards; i++) {
+    sh[i].device = (int)(i % (uint32_t)ndev);
+    sh[i].first = std::min<long>((long)i * share, total);
+    sh[i].count = std::min<long>(share, total - sh[i].first);
+  }
+  (void)cap;
+  for (uint32_t i = 0; i < nshards; i++) th.emplace_back(run_shard, &sh[i], in, n, level, share > 0 ? share : 1);
+  for (auto& t : th) t.join();
+  uint64_t total_bits = 32 + 80;
+  for (auto& x : sh) { if (x.rc) return x.rc; total_bits += x.bits; }
+  const size_t len = (size_t)((total_bits + 7) / 8);
+  uint8_t* o = (uint8_t*)calloc(len + 16, 1);
+  if (!o) return CJS_E_OUT_OF_MEMORY;
+  o[0] = 'B'; o[1] = 'Z'; o[2] = 'h'; o[3] = (uint8_t)('0' + level);
+  uint64_t pos = 32; uint32_t scrc = 0;
+  for (auto& x : sh) {
+    const size_t nbytes = (size_t)((x.bits + 7) / 8);
+    const unsigned s = (unsigned)(pos & 7); size_t ob = (size_t)(pos >> 3);
+    for (size_t i = 0; i < nbytes; i++) {
+      uint8_t b = x.bytes[i];
+      if (i == nbytes - 1 && (x.bits & 7)) b &= (uint8_t)(0xFF << (8 - (x.bits & 7)));
+      o[ob + i] |= (uint8_t)(b >> s);
+      if (s) o[ob + i + 1] |= (uint8_t)(b << (8 - s));
+    }
+    pos += x.bits;
+    for (long k = x.first; k < x.first + x.count; k++) scrc = ((scrc << 1) | (scrc >> 31)) ^ x.crcs[(size_t)k];
+  }
+  const uint64_t trailer[2] = {0x177245385090ull, scrc}; const int tb[2] = {48, 32};
+  for (int q = 0; q < 2; q++) for (int i = tb[q] - 1; i >= 0; i--, pos++) if ((trailer[q] >> i) & 1) o[pos >> 3] |= (uint8_t)(0x80 >> (pos & 7));
+  *out = o; *out_n = len;
+  return 0;
+}
+
 extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
   if (!out || !out_n) return CJS_E_INVALID_ARG;
   *out = nullptr; *out_n = 0;
   if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;                 // J/Bzip2_joined_.js:2208
   CJS_TRY(select_device(opts));
+  uint32_t nshards = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->n_devices : 0;
+  if (const char* e = getenv("CJS_DEVICES")) nshards = (uint32_t)atoi(e);   // lets JS / Python callers shard without an opts struct
+  if (nshards > 1 && n > 0) return compress_multi(in, n, level, nshards > 64 ? 64 : nshards, out, out_n);
   cjs_ctx* c = nullptr;
   CJS_TRY(cjs_ctx_create(&c, -1, n, level));
   const size_t out_cap = (n + n / 4 + 4096 + 3) & ~(size_t)3;

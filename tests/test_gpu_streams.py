@@ -189,3 +189,13 @@ def test_bwtc_decompress_round_trip(hip, oracle, case):
 
 def test_bwtc_errors(hip):
     assert hip.bwtc_decompress(b"nope, not bwtc")[0] == -21
+
+
+def test_multi_device_host_path_equals_single(hip, oracle, monkeypatch):
+    # CJS_DEVICES=3: three worker shards (all on GPU 0 here) + host funnel-shift assembly == the single stream
+    data = recipes.textgen(1500000, 9)
+    rc, want = oracle.bzip2_compress(data, 1)
+    monkeypatch.setenv("CJS_DEVICES", "3")
+    rc, out = hip.bzip2_compress(data, 1)
+    monkeypatch.delenv("CJS_DEVICES")
+    assert rc == 0 and np.array_equal(out, want)

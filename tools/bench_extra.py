@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configs (not the headline line of bench.py):
+   config[1] bzip2 -1 compress 100 MB, config[4] bzip2 -9 decompress, config[3] BWTC -9 compress (with the serial
+   range-coder tail separated), all through the host-buffer C ABI (includes PCIe + workspace allocation).
+   Writes one JSON object to stdout."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401  (one HIP runtime per process)
+import recipes
+import support
+
+pkg = importlib.import_module("compressjs-flattened_amd")
+mb = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+data = recipes.textgen(mb * 1000000, 1)
+res = {"input_bytes": int(data.size), "note": "host-buffer C ABI: H2D + workspace hipMalloc + kernels + D2H, wall clock, best of 3"}
+
+
+def best(fn, reps=3):
+    t = []
+    out = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        t.append(time.perf_counter() - t0)
+    return min(t), out
+
+
+dt, c9 = best(lambda: pkg.Bzip2.compressFile(data, None, 9))
+res["bzip2_9_compress_MBps"] = round(data.size / dt / 1e6, 1)
+dt, c1 = best(lambda: pkg.Bzip2.compressFile(data, None, 1))
+res["bzip2_1_compress_MBps"] = round(data.size / dt / 1e6, 1)
+res["bzip2_1_out_len"] = int(c1.size)
+dt, back = best(lambda: pkg.Bzip2.decompressFile(c9))
+assert np.array_equal(back, data)
+res["bzip2_9_decompress_MBps"] = round(data.size / dt / 1e6, 1)
+dt, back = best(lambda: pkg.Bzip2.decompressFile(c1))
+assert np.array_equal(back, data)
+res["bzip2_1_decompress_MBps"] = round(data.size / dt / 1e6, 1)
+dt, w9 = best(lambda: pkg.BWTC.compressFile(data, None, 9))
+res["bwtc_9_compress_MBps"] = round(data.size / dt / 1e6, 1)
+res["bwtc_9_out_len"] = int(w9.size)
+dt, back = best(lambda: pkg.BWTC.decompressFile(w9), reps=2)
+assert np.array_equal(back, data)
+res["bwtc_9_decompress_MBps"] = round(data.size / dt / 1e6, 1)
+for name in ("golden_big_bzip2_1_%dm.json" % mb, "golden_big_bwtc_9_%dm.json" % mb):
+    p = os.path.join(ROOT, "tests", "golden", name)
+    if os.path.exists(p):
+        g = json.load(open(p))["cases"][0]
+        got = c1 if "bzip2" in name else w9
+        res["bit_exact_" + name] = bool(g["out_len"] == got.size and g["out_sha256"] == support.sha256(got))
+print(json.dumps(res))
