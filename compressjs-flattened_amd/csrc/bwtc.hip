@@ -32,14 +32,17 @@ struct Fen {
   uint32_t* tree; int num_syms;
 };
 // path sum + update (J/BWTC_joined_.js:1547-1562).  Returns lt (all lanes) and tot (old root).
+// lane l owns level l of the path; the <= 10 per-level contributions are summed with scalar readlanes.
 __device__ __forceinline__ void fen_path(const Fen& f, int leaf, uint32_t update, uint32_t& lt, uint32_t& tot) {
   const int lane = lane_id();
   const int node = lane < 16 ? leaf >> lane : 0;       // level `lane` of the path (0 when above the root)
   uint32_t contrib = 0;
   if (node > 1 && (node & 1)) contrib = f.tree[node - 1];
   const uint32_t root = f.tree[1];
-  __builtin_amdgcn_wave_barrier();
-  lt = wave_sum(contrib);
+  uint32_t sum = 0;
+#pragma unroll
+  for (int l = 0; l < 10; l++) sum += (uint32_t)__builtin_amdgcn_readlane((int)contrib, l);   // 2*num_syms <= 516 < 2^10
+  lt = sum;
   tot = root;
   if (node >= 1) f.tree[node] += update;
   __builtin_amdgcn_wave_barrier();
@@ -80,24 +83,26 @@ __device__ void fen_rescale(const Fen& f) {            // _rescale (:1623-1654)
   __builtin_amdgcn_wave_barrier();
   fen_sum_tree(f);
 }
-// encode(symbol) (:1530-1571).  Emits 1 or 2 coder steps into out[*n..]
-__device__ void fen_encode(const Fen& f, int symbol, uint64_t* out, uint32_t& n, bool top_level = true) {
+// one coder step of encode() (:1530-1571): plain symbol, or symbol in the escape distribution (esc_ctx)
+__device__ __forceinline__ void fen_step(const Fen& f, int symbol, bool esc_ctx, uint64_t* out, uint32_t& n) {
   const int leaf = f.num_syms + symbol;
   const uint32_t sy_raw = f.tree[leaf];
   uint32_t mask = 0xFFFF0000u; int shift = 16;
   uint32_t update = F_INC << 16;
-  if ((sy_raw & 0xFFFF0000u) == 0) {                   // escape first, then code in the escape distribution
-    if (top_level) fen_encode(f, f.num_syms - 1, out, n, false);
-    mask = 0x0000FFFFu; update -= 1u; shift = 0;
-  } else if (symbol == f.num_syms - 1 && (f.tree[1] & 0xFFFFu) == 1u) {
-    update = 0u - f.tree[leaf];                        // last escape: zero it out
-  }
+  if (esc_ctx) { mask = 0x0000FFFFu; update -= 1u; shift = 0; }
+  else if (symbol == f.num_syms - 1 && (f.tree[1] & 0xFFFFu) == 1u) update = 0u - sy_raw;     // last escape: zero it out
   uint32_t lt, tot;
   fen_path(f, leaf, update, lt, tot);
   if (lane_id() == 0)
     out[n] = (uint64_t)((sy_raw & mask) >> shift) | ((uint64_t)((lt & mask) >> shift) << 16) | ((uint64_t)((tot & mask) >> shift) << 32);
   n++;
   if ((f.tree[1] >> 16) >= F_MAX) fen_rescale(f);
+}
+// encode(symbol): a symbol whose own count is still zero is announced by the escape symbol first (:1537-1541)
+__device__ __forceinline__ void fen_encode(const Fen& f, int symbol, uint64_t* out, uint32_t& n) {
+  const bool esc = (f.tree[f.num_syms + symbol] & 0xFFFF0000u) == 0;
+  if (esc) fen_step(f, f.num_syms - 1, false, out, n);
+  fen_step(f, symbol, esc, out, n);
 }
 
 __global__ __launch_bounds__(64) void bwtc_fenwick(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps) {
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(64) void bwtc_fenwick(MtfBufs mb, uint64_t* __restr
     const uint32_t mine = base + lane < nsym ? A[base + lane] : 0u;
     const uint32_t cnt = nsym - base < 64 ? nsym - base : 64;
     for (uint32_t j = 0; j < cnt; j++) {
-      const int sym = (int)__shfl(mine, (int)j, 64);
+      const int sym = __builtin_amdgcn_readlane((int)mine, (int)j);
       fen_encode(f, sym, out, n);
     }
   }

@@ -68,14 +68,27 @@ __global__ __launch_bounds__(256) void bz_magic_scan(const uint8_t* __restrict__
 // ---------------------------------------------------------------- 2. block decode (one wave per candidate)
 struct BitReader {
   const uint8_t* p; uint64_t nbits, pos;
-  __device__ __forceinline__ uint32_t peek(int k) const {          // next k <= 25 bits, zeros past EOF (:149)
-    const uint64_t byte = pos >> 3; const uint64_t nbytes = (nbits + 7) >> 3;
+  uint64_t win; uint64_t wbyte;                                      // cached big-endian window of bytes [wbyte, wbyte+8)
+  __device__ __forceinline__ void refill() {
+    wbyte = pos >> 3;
+    const uint64_t nbytes = (nbits + 7) >> 3;
     uint64_t w = 0;
+    if (wbyte + 8 <= nbytes) {
 #pragma unroll
-    for (int i = 0; i < 5; i++) w = (w << 8) | (byte + i < nbytes ? p[byte + i] : 0);
-    return (uint32_t)((w >> (40 - (pos & 7) - k)) & ((1u << k) - 1u));
+      for (int i = 0; i < 8; i++) w = (w << 8) | p[wbyte + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) w = (w << 8) | (wbyte + i < nbytes ? p[wbyte + i] : 0);   // zeros past EOF (:149)
+    }
+    win = w;
   }
-  __device__ __forceinline__ uint32_t get(int k) { const uint32_t v = peek(k); pos += k; if (pos > nbits) pos = nbits; return v; }
+  __device__ __forceinline__ uint32_t peek(int k) {                  // next k <= 25 bits
+    uint64_t off = pos - (wbyte << 3);
+    if (pos < (wbyte << 3) || off + (uint64_t)k > 64) { refill(); off = pos - (wbyte << 3); }
+    return (uint32_t)((win << off) >> (64 - k));
+  }
+  __device__ __forceinline__ void skip(int k) { pos += k; if (pos > nbits) pos = nbits; }
+  __device__ __forceinline__ uint32_t get(int k) { const uint32_t v = peek(k); skip(k); return v; }
 };
 
 struct DecShared {
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
   BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
   if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
   uint8_t* tt = tt_all + (size_t)c * dbuf_size;
-  BitReader r{in, n * 8, cands[c].bit + 48};
+  BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
   int err = 0;
   uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0;
   if (lane == 0) {                                           // header (:1440-1493)
@@ -195,8 +208,13 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
     for (int i = lane; i < 256; i += 64) { S.byte_count[i] = 0; S.mtf[i] = (uint8_t)i; }
   }
   __builtin_amdgcn_wave_barrier();
+  // symbol loop (:1597-1670).  Executed by ALL lanes on identical (wave-uniform) state, so the serial Huffman
+  // decode costs the same as on one lane while the move-to-front shift and the run fills use the 64 lanes.
   uint32_t dbuf_count = 0;
-  if (lane == 0 && !err) {                                   // symbol loop (:1597-1670)
+  r.pos = __shfl((unsigned long long)r.pos, 0, 64);
+  r.wbyte = ~0ull >> 4;
+  orig = __shfl(orig, 0, 64);
+  if (!err) {
     int32_t run_pos = 0; long long run_t = 0;
     uint32_t selector = 0; int sym_left = 0, g = 0;
     for (;;) {
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
       uint32_t next_sym;
       const uint32_t x = r.peek(10);
       const uint16_t e = S.fast[g][x];
-      if (e && e != 0x1F) { next_sym = e >> 5; r.pos += e & 31; if (r.pos > r.nbits) r.pos = r.nbits; }
+      if (e && e != 0x1F) { next_sym = e >> 5; r.skip(e & 31); }
       else if (e == 0x1F) { err = CJS_E_DATA_ERROR; break; }
       else {                                                 // long code: the reference's bit-by-bit rule
         int i = S.minlen[g];
@@ -234,18 +252,32 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
         run_pos = 0;
         if ((long long)dbuf_count + run_t > (long long)dbuf_size) { err = CJS_E_DATA_ERROR; break; }
         const uint8_t uc = S.sym_to_byte[S.mtf[0]];
-        S.byte_count[uc] += (uint32_t)run_t;
-        for (long long q = 0; q < run_t; q++) tt[dbuf_count++] = uc;
+        const uint32_t old = S.byte_count[uc];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) S.byte_count[uc] = old + (uint32_t)run_t;
+        for (long long q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
+        dbuf_count += (uint32_t)run_t;
       }
       if (next_sym > sym_total) break;                        // EOB
       if (dbuf_count >= dbuf_size) { err = CJS_E_DATA_ERROR; break; }
-      uint32_t k = next_sym - 1;
+      const uint32_t k = next_sym - 1;
       const uint8_t v = S.mtf[k];
-      for (; k > 0; k--) S.mtf[k] = S.mtf[k - 1];
-      S.mtf[0] = v;
+      __builtin_amdgcn_wave_barrier();
+      // move to front: slots 1..k take the value of their left neighbour, highest indices first, 64 per step
+      for (int hi = (int)k; hi >= 1; hi -= 64) {
+        const int idx = hi - lane;
+        uint8_t t8 = 0;
+        if (idx >= 1) t8 = S.mtf[idx - 1];
+        __builtin_amdgcn_wave_barrier();
+        if (idx >= 1) S.mtf[idx] = t8;
+        __builtin_amdgcn_wave_barrier();
+      }
       const uint8_t uc = S.sym_to_byte[v];
-      S.byte_count[uc]++;
-      tt[dbuf_count++] = uc;
+      const uint32_t oldc = S.byte_count[uc];
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { S.mtf[0] = v; S.byte_count[uc] = oldc + 1; tt[dbuf_count] = uc; }
+      __builtin_amdgcn_wave_barrier();
+      dbuf_count++;
     }
     if (!err && orig >= dbuf_count) err = CJS_E_DATA_ERROR;    // :1677
   }
