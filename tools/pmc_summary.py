@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes, as MI355X_MICROARCH.md prescribes).
+usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <launches to skip (warm-up step)> > json
+Units: FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 correction: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads
+(TCC_EA0_RDREQ x 64 B with 128-B requests tallied at 64 B), so the read side is doubled; WRITE_SIZE is exact."""
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        n = r["Kernel_Name"].split("(")[0].replace("cjs::", "").replace("void ", "")
+        a = acc.setdefault(n, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return acc
+
+
+f = per_kernel(sys.argv[1], "FETCH_SIZE")
+w = per_kernel(sys.argv[2], "WRITE_SIZE")
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+out = {"steps_in_profile": steps, "note": "per step; bytes = KiB*1024; fetch doubled per the gfx950 FETCH_SIZE correction", "kernels": {}}
+tot = 0.0
+for k in sorted(set(f) | set(w)):
+    fb = 2.0 * f.get(k, [0, 0.0])[1] * 1024 / steps
+    wb = w.get(k, [0, 0.0])[1] * 1024 / steps
+    calls = max(f.get(k, [0, 0])[0], w.get(k, [0, 0])[0]) / steps
+    out["kernels"][k] = {"launches_per_step": calls, "fetch_bytes_per_step": round(fb), "write_bytes_per_step": round(wb),
+                         "hbm_bytes_per_launch": round((fb + wb) / calls) if calls else 0}
+    if k.startswith(("rs_", "bwt_", "rle_", "mtf_", "huff_", "pack_")):
+        tot += fb + wb
+out["pipeline_hbm_bytes_per_step"] = round(tot)
+k = "rs_scatter<unsigned long>"
+if k in out["kernels"]:
+    out["rs_scatter_hbm_bytes_per_launch"] = out["kernels"][k]["hbm_bytes_per_launch"]
+print(json.dumps(out, indent=1))
