@@ -148,6 +148,129 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
 }
 
 // ------------------------------------------------------------------------------------------
+// Single-pass-per-digit variant ("onesweep"): digit histograms of ALL passes are taken in one read of the
+// keys (digit counts do not depend on the order), and each scatter pass gets its tile offsets by decoupled
+// look-back over per-tile status words instead of a separate histogram + scan pass:
+//   status[tile][digit] = flag(2) | count(30): 1 = this tile's count, 2 = inclusive prefix up to this tile.
+// Tiles take their index from an atomic ticket, so every lower-numbered tile is already resident when a
+// tile waits on it.  Status words are single 4-byte agent-scope (sc1) atomics: value and flag travel together
+// (MI355X: per-XCD L2s are not coherent, see cdna_hip_programming.md Guideline 16 R2).  Spins are bounded.
+// ------------------------------------------------------------------------------------------
+template <typename K>
+__global__ __launch_bounds__(256) void rs_ghist(const K* __restrict__ keys, uint32_t n, int lo_bit, int npasses, uint32_t* __restrict__ ghist, uint32_t T) {
+  __shared__ uint32_t h[8][256];
+  for (int i = threadIdx.x; i < 8 * 256; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    const uint64_t base = (uint64_t)tile * RS_TILE;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+      const uint64_t idx = base + (uint32_t)it * 256 + threadIdx.x;
+      if (idx < n) {
+        const K k = keys[idx];
+        for (int p = 0; p < npasses; p++) atomicAdd(&h[p][(uint32_t)(k >> (lo_bit + 8 * p)) & 255u], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < npasses; p++) { const uint32_t v = h[p][threadIdx.x]; if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], v); }
+}
+__global__ __launch_bounds__(256) void rs_gscan(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ gbase) {
+  __shared__ uint32_t sm[4];
+  uint32_t tot;
+  gbase[blockIdx.x * 256 + threadIdx.x] = block_excl_sum<256>(ghist[blockIdx.x * 256 + threadIdx.x], sm, tot);
+}
+
+constexpr uint32_t OS_MASK = (1u << 30) - 1u;
+template <typename K>
+__global__ __launch_bounds__(256) void rs_onesweep(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                   K* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
+                                                   const uint32_t* __restrict__ gbase, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                   uint32_t* __restrict__ errflag) {
+  __shared__ K skey[RS_TILE];
+  __shared__ uint32_t sval[RS_TILE];
+  __shared__ uint32_t wcnt[4][256];
+  __shared__ uint32_t goff[256];
+  __shared__ uint32_t sm[4];
+  __shared__ uint32_t tile_s;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  if (tid == 0) tile_s = atomicAdd(ticket, 1u);
+  for (int i = tid; i < 1024; i += 256) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t tile = tile_s;
+  const uint64_t base = (uint64_t)tile * RS_TILE;
+  const uint32_t nvalid = (uint32_t)((uint64_t)n - base < RS_TILE ? (uint64_t)n - base : RS_TILE);
+  K k[16];
+  uint32_t v[16];
+  uint32_t rk[16];
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+    const bool ok = loc < nvalid;
+    k[s] = ok ? kin[base + loc] : (K)~(K)0;
+    v[s] = ok ? vin[base + loc] : 0u;
+  }
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
+    const uint64_t peers = match_any8(d);
+    const uint32_t prior = wcnt[w][d];
+    const uint32_t r = (uint32_t)__popcll(peers & lt);
+    rk[s] = prior + r;
+    __builtin_amdgcn_wave_barrier();
+    if (r == 0) wcnt[w][d] = prior + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {
+    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+    // the padding elements of the last tile carry digit 255: they must not be counted
+    const uint32_t pad = (tid == 255) ? RS_TILE - nvalid : 0u;
+    const uint32_t mine = c0 + c1 + c2 + c3 - pad;
+    uint32_t total;
+    const uint32_t ex = block_excl_sum<256>(c0 + c1 + c2 + c3, sm, total);
+    uint32_t* st = status + (size_t)tile * 256 + tid;
+    uint32_t prefix = 0;
+    if (tile == 0) __hip_atomic_store(st, (2u << 30) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      __hip_atomic_store(st, (1u << 30) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t t = tile - 1, spins = 0;
+      for (;;) {
+        const uint32_t sv = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t f = sv >> 30;
+        if (f == 2u) { prefix += sv & OS_MASK; break; }
+        if (f == 1u) { prefix += sv & OS_MASK; t--; spins = 0; continue; }
+        if (++spins > (1u << 22)) { *errflag = 1u; break; }     // cannot happen: the predecessor tile is resident
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __hip_atomic_store(st, (2u << 30) | ((prefix + mine) & OS_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wcnt[0][tid] = ex; wcnt[1][tid] = ex + c0; wcnt[2][tid] = ex + c0 + c1; wcnt[3][tid] = ex + c0 + c1 + c2;
+    goff[tid] = gbase[tid] + prefix - ex;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
+    const uint32_t p = wcnt[w][d] + rk[s];
+    skey[p] = k[s];
+    sval[p] = v[s];
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint32_t j = (uint32_t)it * 256u + tid;
+    if (j < nvalid) {
+      const K kk = skey[j];
+      const uint32_t dst = goff[(uint32_t)(kk >> shift) & 255u] + j;
+      kout[dst] = kk;
+      vout[dst] = sval[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // suffix-sort kernels
 // ------------------------------------------------------------------------------------------
 // round 0 keys: (block id, first nsym symbols).  cyclic: bytes wrap; sentinel: 9-bit symbols, 0 = past the end
@@ -369,7 +492,7 @@ size_t BwtWork::bytes_needed(size_t cap) {
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
   add(cap * 8); add(cap * 8); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4);  // key x2, val x2, pos x2, gord
   add(cap * 4); add(cap * 4);           // R, SA
-  add(256 * T * 4); add(256 * 4); add(3 * T * 4); add(64);
+  add(256 * T * 4); add(256 * 4); add(3 * T * 4); add(64); add(16 * 256 * 4);
   return b + 4096;
 }
 int BwtWork::carve(Arena& a, size_t cap_) {
@@ -382,7 +505,8 @@ int BwtWork::carve(Arena& a, size_t cap_) {
   R = a.take<uint32_t>(cap); SA = a.take<uint32_t>(cap);
   hist = a.take<uint32_t>(256 * T); bintot = a.take<uint32_t>(256);
   tile_cnt = a.take<uint32_t>(3 * T); counters = a.take<uint32_t>(16);
-  if (!counters) return CJS_E_OUT_OF_MEMORY;
+  ghist = a.take<uint32_t>(16 * 256);
+  if (!counters || !ghist) return CJS_E_OUT_OF_MEMORY;
   if (!h_counters) CJS_HIP_TRY(hipHostMalloc((void**)&h_counters, 64));
   return 0;
 }
@@ -414,6 +538,30 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
                         LaunchTimes* lt) {
   const uint32_t T = (n + RS_TILE - 1) / RS_TILE;
   K* kk[2] = {k0, k1}; uint32_t* vv[2] = {v0, v1};
+  const int npasses = (hi_bit - lo_bit + 7) / 8;
+  // Measured on MI355X (100 MB, level 9): the look-back passes are correct but slower than the three-kernel
+  // passes (BWT 26.4 ms vs 23.2 ms: one lane per digit walks predecessor tiles serially, ~1 us per sc1 poll),
+  // so they stay opt-in until the look-back is widened to a wave per window.
+  static const bool classic = getenv("CJS_ONESWEEP") == nullptr;
+  if (!classic && w.ghist && npasses >= 1 && npasses <= 8 && n < (1u << 30)) {
+    // one histogram read for all digits + look-back scatter passes
+    uint32_t* gbase = w.ghist + 8 * 256;
+    uint32_t* ticket = w.counters + 8; uint32_t* errflag = w.counters + 9;
+    CJS_HIP_TRY(hipMemsetAsync(w.ghist, 0, 8 * 256 * 4, s));
+    hipLaunchKernelGGL(rs_ghist<K>, dim3(T < 2048u ? T : 2048u), dim3(256), 0, s, kk[cur], n, lo_bit, npasses, w.ghist, T);
+    hipLaunchKernelGGL(rs_gscan, dim3(npasses), dim3(256), 0, s, w.ghist, gbase);
+    for (int p = 0; p < npasses; p++) {
+      CJS_HIP_TRY(hipMemsetAsync(w.hist, 0, (size_t)T * 256 * 4, s));
+      CJS_HIP_TRY(hipMemsetAsync(ticket, 0, 4, s));
+      if (lt) lt->begin(s, n);
+      hipLaunchKernelGGL(rs_onesweep<K>, dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], n, lo_bit + 8 * p,
+                         gbase + p * 256, w.hist, ticket, errflag);
+      if (lt) lt->end(s);
+      cur = 1 - cur;
+    }
+    CJS_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   for (int shift = lo_bit; shift < hi_bit; shift += 8) {
     hipLaunchKernelGGL(rs_hist<K>, dim3(T), dim3(256), 0, s, kk[cur], n, shift, w.hist, T);
     hipLaunchKernelGGL(rs_scan_bins, dim3(256), dim3(1024), 0, s, w.hist, T, w.bintot);
@@ -446,6 +594,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   LaunchTimes lt; lt.enabled = stats != nullptr;
 
   int c = 0, pc = 0;        // current key/val buffer, current pos buffer
+  CJS_HIP_TRY(hipMemsetAsync(w.counters, 0, 64, s));
   // round 0 sorts by as many leading symbols as fit beside the block id in 64 bits
   const int blk_bits = bits_for(nb - 1), sym_bits = cyclic ? 8 : 9;
   int nsym = (64 - blk_bits) / sym_bits;
@@ -460,10 +609,11 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters);
     hipLaunchKernelGGL(bwt_apply, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                        w.val[1 - c], w.pos[1 - pc], w.gord);
-    CJS_HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters, 8, hipMemcpyDeviceToHost, s));
+    CJS_HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters, 40, hipMemcpyDeviceToHost, s));
     CJS_HIP_TRY(hipStreamSynchronize(s));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
+    if (w.h_counters[9]) { fprintf(stderr, "[cjs_hip] radix look-back timed out\n"); return CJS_E_HIP; }
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt] round %u h=%u A=%u bits=%d -> A'=%u groups=%u\n", rounds, h, A, bits, A2, NG);
     c = 1 - c; pc = 1 - pc;
     A = A2;

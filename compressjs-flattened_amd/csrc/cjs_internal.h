@@ -61,7 +61,8 @@ struct BwtWork {
   uint32_t* hist = nullptr;      // 256 * tiles
   uint32_t* bintot = nullptr;    // 256
   uint32_t* tile_cnt = nullptr;  // 3 * tiles (+ scanned copies)
-  uint32_t* counters = nullptr;  // 16
+  uint32_t* counters = nullptr;  // 16: [0] survivors [1] groups [8] tile ticket [9] look-back error
+  uint32_t* ghist = nullptr;     // [8][256] digit histograms + [8][256] their exclusive scans (onesweep passes)
   uint32_t* h_counters = nullptr;  // pinned host mirror
   static size_t bytes_needed(size_t cap);
   int carve(Arena& a, size_t cap);

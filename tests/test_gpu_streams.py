@@ -199,3 +199,29 @@ def test_multi_device_host_path_equals_single(hip, oracle, monkeypatch):
     rc, out = hip.bzip2_compress(data, 1)
     monkeypatch.delenv("CJS_DEVICES")
     assert rc == 0 and np.array_equal(out, want)
+
+
+def test_onesweep_variant_is_bit_exact(hip, oracle, monkeypatch):
+    # the opt-in look-back radix passes must give the same stream
+    data = recipes.textgen(2500000, 4)
+    rc, want = oracle.bzip2_compress(data, 9)
+    import subprocess, sys as _sys
+    code = ("import sys; sys.path.insert(0, 'tests'); import torch, support, recipes, numpy as np; "
+            "d = recipes.textgen(2500000, 4); rc, out = support.HipLib().bzip2_compress(d, 9); "
+            "print(rc, support.sha256(out))")
+    env = dict(os.environ, CJS_ONESWEEP="1")
+    out = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rc_s, sha = out.stdout.split()
+    assert rc_s == "0" and sha == support.sha256(want)
+
+
+@pytest.mark.slow
+def test_1gib_bzip2_golden(hip):
+    # BASELINE.json north_star: bit-identical .bz2 on a 1 GiB enwik8-shaped input (golden cut by the reference JS)
+    case = support.load_golden("golden_big_bzip2_9_1g.json")["cases"][0]
+    data = recipes.build(case["recipe"])
+    assert support.sha256(data) == case["in_sha256"]
+    rc, out = hip.bzip2_compress(data, 9)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == case["out_len"] and support.sha256(out) == case["out_sha256"]
