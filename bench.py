@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--mb", type=int, default=100, help="input MB (10^6 bytes) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barriers (nccl = RCCL)")
     args = ap.parse_args()
 
     import torch
@@ -66,10 +67,15 @@ def main():
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     n_gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    if os.environ.get("BENCH_FORCE_DEVICE0"):      # rehearsal of the N>1 path on a one-GPU box (use with --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     pkg = importlib.import_module("compressjs-flattened_amd")
     import recipes
@@ -126,7 +132,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
