@@ -17,6 +17,8 @@ struct Rle1Work {
   uint32_t cap = 0, max_blocks = 0, max_segs = 0, range_blocks = 0;
   uint32_t* h_n = nullptr;       // pinned host scalar
   uint64_t *fb = nullptr, *lb = nullptr, *gt = nullptr;
+  uint16_t* subpre = nullptr;    // [tiles][16] emitted bytes of the tile before each 256-byte subtile
+  uint8_t* dmod = nullptr;       // [tiles][16] chunk phase of each subtile's first byte
   RleBlock* blocks = nullptr;
   uint32_t *block_len = nullptr, *block_crc = nullptr, *nblocks = nullptr, *seg_crc = nullptr;
   static size_t max_blocks_for(size_t max_in, uint32_t cap) { return max_in / ((size_t)cap * 4 / 5) + 2; }

@@ -121,14 +121,17 @@ __global__ __launch_bounds__(1024) void rle_scan_boundaries(uint64_t* __restrict
   }
 }
 
-// ---- P3: per-tile emitted byte count under the global chunking
+// ---- P3: per-tile emitted byte count under the global chunking, plus two small tables per 256-byte subtile
+//          (used by the speculative boundary search): subpre = emitted bytes of the tile before the subtile,
+//          dmod = chunk phase (offset in run mod 255) of the subtile's first byte
 __global__ __launch_bounds__(256) void rle_tile_count(const uint8_t* __restrict__ in, uint64_t N, const uint64_t* __restrict__ run_start_in,
-                                                      uint64_t* __restrict__ gt) {
+                                                      uint64_t* __restrict__ gt, uint16_t* __restrict__ subpre, uint8_t* __restrict__ dmod) {
   __shared__ uint32_t smem[256 + 16];
   const uint64_t tile_start = (uint64_t)blockIdx.x * RT;
   uint8_t b[16]; uint32_t bm; uint64_t rs;
   run_starts<256, 16>(in, N, tile_start, run_start_in[blockIdx.x], smem, b, bm, rs);
   const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * 16;
+  if ((threadIdx.x & 15) == 0) dmod[(size_t)blockIdx.x * 16 + (threadIdx.x >> 4)] = (uint8_t)(p0 < N ? (((bm & 1u) ? 0ull : p0 - rs) % 255) : 0);
   uint32_t cnt = 0;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
@@ -139,8 +142,10 @@ __global__ __launch_bounds__(256) void rle_tile_count(const uint8_t* __restrict_
       cnt += dp < 3 ? 1u : dp == 3 ? 2u : 0u;
     }
   }
-  cnt = block_sum<256>(cnt, smem);
-  if (threadIdx.x == 0) gt[blockIdx.x] = cnt;
+  uint32_t tot;
+  const uint32_t ex = block_excl_sum<256>(cnt, smem, tot);
+  if ((threadIdx.x & 15) == 0) subpre[(size_t)blockIdx.x * 16 + (threadIdx.x >> 4)] = (uint16_t)ex;
+  if (threadIdx.x == 0) gt[blockIdx.x] = tot;
 }
 
 // ---- P4: exclusive prefix sum (u64) over tiles, one workgroup; gt[Tn] = total
@@ -198,15 +203,92 @@ __device__ void walk_tile_eval(const uint8_t* __restrict__ in, uint64_t N, uint6
 }
 
 // ---- W: block boundaries.  ONE workgroup, serial over blocks.
+// Speculative boundary search: from a block start s0 that coincides with a run boundary (fresh chunking == global
+// chunking), the next boundaries are where G reaches G(s0) + j*cap.  Lane j looks its boundary up on its own
+// (binary search on G_tile, then the subtile table, then <= 256 bytes serially).  A boundary is "clean" when G hits
+// the target exactly and the next block again starts on a run boundary; blocks up to the first unclean boundary
+// are exact, the unclean one is resolved by one serial step of the general rule, and speculation resumes.
+struct SpecOut { uint64_t e; uint32_t clean; uint32_t eof; uint32_t len_last; };
+__device__ SpecOut spec_boundary(const uint8_t* __restrict__ in, uint64_t N, uint32_t Tn, const uint64_t* __restrict__ gt,
+                                 const uint16_t* __restrict__ subpre, const uint8_t* __restrict__ dmod, uint64_t target, uint64_t prev_target) {
+  SpecOut o; o.e = N; o.clean = 0; o.eof = 0; o.len_last = 0;
+  if (gt[Tn] < target) { o.eof = 1; o.len_last = gt[Tn] > prev_target ? (uint32_t)(gt[Tn] - prev_target) : 0u; return o; }
+  uint32_t lo = 0, hi = Tn;                       // last tile with gt[t] < target   (gt[0] = 0 < target)
+  while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (gt[mid] < target) lo = mid; else hi = mid; }
+  const uint64_t need = target - gt[lo];          // 1 .. tile count
+  uint32_t sb = 0;
+  for (uint32_t q = 1; q < 16; q++) if ((uint64_t)subpre[(size_t)lo * 16 + q] < need) sb = q;
+  uint64_t p = (uint64_t)lo * RT + (uint64_t)sb * 256;
+  uint64_t acc = subpre[(size_t)lo * 16 + sb];
+  uint32_t dm = dmod[(size_t)lo * 16 + sb];
+  uint8_t prev = in[p];
+  for (uint32_t q = 0; q < 256 && p < N; q++, p++) {
+    const uint8_t c = in[p];
+    if (q) dm = (c != prev) ? 0u : (dm + 1u == 255u ? 0u : dm + 1u);
+    prev = c;
+    acc += dm < 3 ? 1u : dm == 3 ? 2u : 0u;
+    if (acc >= need) {
+      o.e = p + 1;
+      const bool exact = acc == need;
+      const bool next_fresh = p + 1 >= N || in[p + 1] != c;
+      o.clean = exact && next_fresh;
+      return o;
+    }
+  }
+  o.e = p;             // not reached (tables inconsistent): treated as unclean at this position
+  return o;
+}
+
 __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in, uint64_t N, uint32_t cap, uint32_t Tn,
                                                  const uint64_t* __restrict__ run_start_in, const uint64_t* __restrict__ next_bnd,
-                                                 const uint64_t* __restrict__ gt, RleBlock* __restrict__ blocks, uint32_t max_blocks,
-                                                 uint32_t* __restrict__ nblocks_out) {
+                                                 const uint64_t* __restrict__ gt, const uint16_t* __restrict__ subpre, const uint8_t* __restrict__ dmod,
+                                                 RleBlock* __restrict__ blocks, uint32_t max_blocks, uint32_t* __restrict__ nblocks_out) {
   __shared__ uint32_t smem[1024 + 16];
   __shared__ unsigned long long sh64[2];
+  __shared__ unsigned long long spec_e[1024];
+  __shared__ uint32_t spec_first_bad;
   uint64_t s = 0;
   uint32_t k = 0;
-  while (s < N && k < max_blocks) {
+  bool done = false;
+  while (s < N && k < max_blocks && !done) {
+    // ---- speculative rounds: only from a run boundary
+    if (s == 0 || in[s] != in[s - 1]) {
+      // G(s): tile prefix + in-tile prefix (one cooperative tile evaluation)
+      const uint32_t t0 = (uint32_t)(s / RT);
+      uint64_t fp; uint32_t below;
+      walk_tile_eval(in, N, (uint64_t)t0 * RT, run_start_in[t0], 0, NONE64, s, smem, sh64, fp, below);
+      const uint64_t G0 = gt[t0] + below;
+      const uint32_t j = threadIdx.x;
+      if (j == 0) spec_first_bad = 1024;
+      __syncthreads();
+      SpecOut so = spec_boundary(in, N, Tn, gt, subpre, dmod, G0 + (uint64_t)(j + 1) * cap, G0 + (uint64_t)j * cap);
+      spec_e[j] = so.e;
+      if (!so.clean || so.eof) atomicMin(&spec_first_bad, j);
+      __syncthreads();
+      const uint32_t m = spec_first_bad;                    // boundaries 0..m-1 are clean; boundary m is EOF or unclean
+      // blocks k+j for j <= m (block j spans (boundary j-1, boundary j]); the one ending at boundary m is still exact
+      if (j <= m && j < 1024 && k + j < max_blocks) {
+        const uint64_t bs = j == 0 ? s : spec_e[j - 1];
+        RleBlock bd; bd.s = bs; bd.r_end = bs; bd.base = 0; bd.Gr = G0 + (uint64_t)j * cap;
+        bool emit = true;
+        if (so.eof) { bd.e = N; bd.len = so.len_last; emit = so.len_last > 0 && bs < N; }
+        else { bd.e = so.e; bd.len = cap; }
+        if (j < m || (j == m && m < 1024)) { if (emit) blocks[k + j] = bd; }
+      }
+      __syncthreads();
+      // advance: count emitted blocks
+      if (m < 1024) {
+        // boundary m: EOF (stream ends) or unclean (continue with the general rule from its end)
+        const unsigned long long e_m = spec_e[m];
+        // was block m emitted?  eof with zero length -> not
+        const uint64_t tgt_prev = G0 + (uint64_t)m * cap;
+        const bool eof_m = gt[Tn] < tgt_prev + cap;
+        if (eof_m) { const bool has = gt[Tn] > tgt_prev && (m == 0 ? s : spec_e[m - 1]) < N; k += m + (has ? 1u : 0u); done = true; }
+        else { k += m + 1; s = e_m; }
+      } else { k += 1024; s = spec_e[1023]; }
+      __syncthreads();
+      continue;
+    }
     // end of the run containing s
     const uint32_t ts = (uint32_t)(s / RT);
     const uint64_t tile_end = ((uint64_t)(ts + 1) * RT < N) ? (uint64_t)(ts + 1) * RT : N;
@@ -452,7 +534,7 @@ size_t Rle1Work::bytes_needed(size_t max_in, uint32_t cap, size_t range_blocks) 
   const size_t segs = max_segs_for(cap);
   size_t b = 0;
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
-  add(Tn * 8); add(Tn * 8); add((Tn + 1) * 8);
+  add(Tn * 8); add(Tn * 8); add((Tn + 1) * 8); add(Tn * 16 * 2); add(Tn * 16);
   add(maxb * sizeof(RleBlock)); add(maxb * 4); add(maxb * 4); add(64);
   add((range_blocks ? range_blocks : maxb) * segs * 4);
   return b + 4096;
@@ -463,6 +545,7 @@ int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_, size_t range_blocks
   max_blocks = (uint32_t)max_blocks_for(max_in, cap);
   max_segs = (uint32_t)max_segs_for(cap);
   fb = a.take<uint64_t>(Tn); lb = a.take<uint64_t>(Tn); gt = a.take<uint64_t>(Tn + 1);
+  subpre = a.take<uint16_t>(Tn * 16); dmod = a.take<uint8_t>(Tn * 16);
   blocks = a.take<RleBlock>(max_blocks); block_len = a.take<uint32_t>(max_blocks); block_crc = a.take<uint32_t>(max_blocks);
   nblocks = a.take<uint32_t>(16);
   range_blocks = (uint32_t)(range_blocks_ ? range_blocks_ : max_blocks);
@@ -488,9 +571,9 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32
   const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
   hipLaunchKernelGGL(rle_tile_summary, dim3(Tn), dim3(256), 0, s, d_in, N, w.fb, w.lb);
   hipLaunchKernelGGL(rle_scan_boundaries, dim3(1), dim3(1024), 0, s, w.fb, w.lb, Tn, N);
-  hipLaunchKernelGGL(rle_tile_count, dim3(Tn), dim3(256), 0, s, d_in, N, w.lb, w.gt);
+  hipLaunchKernelGGL(rle_tile_count, dim3(Tn), dim3(256), 0, s, d_in, N, w.lb, w.gt, w.subpre, w.dmod);
   hipLaunchKernelGGL(rle_scan_counts, dim3(1), dim3(1024), 0, s, w.gt, Tn);
-  hipLaunchKernelGGL(rle_walk, dim3(1), dim3(1024), 0, s, d_in, N, w.cap, Tn, w.lb, w.fb, w.gt, w.blocks, w.max_blocks, w.nblocks);
+  hipLaunchKernelGGL(rle_walk, dim3(1), dim3(1024), 0, s, d_in, N, w.cap, Tn, w.lb, w.fb, w.gt, w.subpre, w.dmod, w.blocks, w.max_blocks, w.nblocks);
   hipLaunchKernelGGL(rle_block_lens, dim3((w.max_blocks + 255) / 256), dim3(256), 0, s, w.blocks, w.nblocks, w.block_len);
   CJS_HIP_TRY(hipGetLastError());
   if (!w.h_n) CJS_HIP_TRY(hipHostMalloc((void**)&w.h_n, 16));
