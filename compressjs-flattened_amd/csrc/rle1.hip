@@ -464,8 +464,7 @@ __global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict
   const uint32_t k = first + blockIdx.y;
   if (k >= *nblocks_p) return;
   const RleBlock bd = blocks[k];
-  const uint64_t seg_start = bd.s + (uint64_t)blockIdx.x * CRC_SEG;
-  if (seg_start >= bd.e) return;
+  if (bd.s + (uint64_t)blockIdx.x * CRC_SEG >= bd.e) return;
   {
     uint32_t c = (uint32_t)threadIdx.x << 24;
     for (int i = 0; i < 8; i++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : (c << 1);
@@ -477,30 +476,36 @@ __global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict
     tab[t][threadIdx.x] = (p << 8) ^ tab[0][p >> 24];
     __syncthreads();
   }
-  const uint64_t a = seg_start + (uint64_t)threadIdx.x * 64;
-  uint64_t bend = a + 64; if (bend > bd.e) bend = bd.e;
-  uint32_t crc = 0;
-  uint64_t p = a;
-  for (; p + 4 <= bend; p += 4) {
-    const uint32_t x = crc ^ (((uint32_t)in[p] << 24) | ((uint32_t)in[p + 1] << 16) | ((uint32_t)in[p + 2] << 8) | (uint32_t)in[p + 3]);
-    crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 0xff] ^ tab[1][(x >> 8) & 0xff] ^ tab[0][x & 0xff];
-  }
-  for (; p < bend; p++) crc = (crc << 8) ^ tab[0][((crc >> 24) ^ in[p]) & 0xff];
-  part[threadIdx.x] = crc;
-  __syncthreads();
-  // tree combine: node (t, width w) = combine(left part[t], right part[t+w]) where right covers bytes
-  // [a + 64w, a + 128w) clipped to e
-  for (uint32_t wdt = 1; wdt < 256; wdt <<= 1) {
-    if ((threadIdx.x & (2 * wdt - 1)) == 0) {
-      const uint64_t rstart = seg_start + (uint64_t)(threadIdx.x + wdt) * 64;
-      if (rstart < bd.e) {
-        uint64_t rend = rstart + (uint64_t)wdt * 64; if (rend > bd.e) rend = bd.e;
-        part[threadIdx.x] = gf_mul(part[threadIdx.x], gf_xpow8(rend - rstart)) ^ part[threadIdx.x + wdt];
-      }
+  // gridDim.x workgroups per block stride over its 16 KiB segments (a block of plain text has ~55 of them, a block
+  // of one long run up to 2,800)
+  for (uint32_t sgi = blockIdx.x; bd.s + (uint64_t)sgi * CRC_SEG < bd.e; sgi += gridDim.x) {
+    const uint64_t seg_start = bd.s + (uint64_t)sgi * CRC_SEG;
+    const uint64_t a = seg_start + (uint64_t)threadIdx.x * 64;
+    uint64_t bend = a + 64; if (bend > bd.e) bend = bd.e;
+    uint32_t crc = 0;
+    uint64_t p = a;
+    for (; p + 4 <= bend; p += 4) {
+      const uint32_t x = crc ^ (((uint32_t)in[p] << 24) | ((uint32_t)in[p + 1] << 16) | ((uint32_t)in[p + 2] << 8) | (uint32_t)in[p + 3]);
+      crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 0xff] ^ tab[1][(x >> 8) & 0xff] ^ tab[0][x & 0xff];
     }
+    for (; p < bend; p++) crc = (crc << 8) ^ tab[0][((crc >> 24) ^ in[p]) & 0xff];
+    part[threadIdx.x] = crc;
+    __syncthreads();
+    // tree combine: node (t, width w) = combine(left part[t], right part[t+w]) where right covers bytes
+    // [a + 64w, a + 128w) clipped to e
+    for (uint32_t wdt = 1; wdt < 256; wdt <<= 1) {
+      if ((threadIdx.x & (2 * wdt - 1)) == 0) {
+        const uint64_t rstart = seg_start + (uint64_t)(threadIdx.x + wdt) * 64;
+        if (rstart < bd.e) {
+          uint64_t rend = rstart + (uint64_t)wdt * 64; if (rend > bd.e) rend = bd.e;
+          part[threadIdx.x] = gf_mul(part[threadIdx.x], gf_xpow8(rend - rstart)) ^ part[threadIdx.x + wdt];
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) seg_crc[(size_t)blockIdx.y * max_segs + sgi] = part[0];
     __syncthreads();
   }
-  if (threadIdx.x == 0) seg_crc[(size_t)blockIdx.y * max_segs + blockIdx.x] = part[0];
 }
 
 __global__ void rle_crc_final(const RleBlock* __restrict__ blocks, const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
@@ -557,7 +562,7 @@ int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_, size_t range_blocks
 int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, const uint32_t* d_nblocks, uint32_t count, uint32_t max_segs,
                uint32_t* d_seg_crc, uint32_t* d_crc_out) {
   if (!count) return 0;
-  hipLaunchKernelGGL(rle_crc_partial, dim3(max_segs, count), dim3(256), 0, s, d_data, d_blocks, d_nblocks, max_segs, 0u, d_seg_crc);
+  hipLaunchKernelGGL(rle_crc_partial, dim3(64, count), dim3(256), 0, s, d_data, d_blocks, d_nblocks, max_segs, 0u, d_seg_crc);
   hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, s, d_blocks, d_nblocks, max_segs, 0u, count, d_seg_crc, d_crc_out);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
@@ -589,7 +594,7 @@ int rle1_finish(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uin
   if (count > w.range_blocks) return CJS_E_INVALID_ARG;
   const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
   hipLaunchKernelGGL(rle_materialize, dim3(Tn), dim3(256), 0, s, d_in, N, w.cap, w.lb, w.fb, w.gt, w.blocks, w.nblocks, first, count, d_blocks);
-  hipLaunchKernelGGL(rle_crc_partial, dim3(w.max_segs, count), dim3(256), 0, s, d_in, w.blocks, w.nblocks, w.max_segs, first, w.seg_crc);
+  hipLaunchKernelGGL(rle_crc_partial, dim3(64, count), dim3(256), 0, s, d_in, w.blocks, w.nblocks, w.max_segs, first, w.seg_crc);
   hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, s, w.blocks, w.nblocks, w.max_segs, first, count, w.seg_crc, w.block_crc);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
