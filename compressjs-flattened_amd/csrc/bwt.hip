@@ -446,6 +446,169 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Rounds >= 2: most unresolved groups are tiny, and the array is already ordered by group, so only the order
+// INSIDE each group is missing.  bwt_tile_sort sorts every group of <= 1024 suffixes in LDS: a tile owns the
+// groups whose head lies in its nominal 3072-slot range and loads a 4096-slot window (1024 slots of slack behind
+// the nominal range, so every owned group is complete).  Tiles whose owned groups all have <= 64 members rank
+// every member by counting inside its group; other tiles bitonic-sort the window on (head slot, rank key, suffix):
+// slots that are not owned carry their own slot number and stay where they are.
+// Groups of > 1024 suffixes keep their defer flag (preset to 1 by the host) and go through the global radix
+// passes (compact -> sort -> scatter back).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t TS_WIN = 4096, TS_MAXGRP = 1024, TS_NOM = TS_WIN - TS_MAXGRP, TS_TINY = 64, TS_GT = 2048;
+__global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
+                                                     uint8_t* __restrict__ dflag) {
+  __shared__ uint64_t sk[TS_WIN];
+  __shared__ uint32_t gk[TS_WIN];
+  __shared__ uint64_t hm[64], om[64];            // head mask, owned(+sortable) mask
+  __shared__ int32_t wlast[64], wnext[64];       // last head before word / first head after word (window slot, -1 / TS_WIN+1 = none)
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const uint64_t wb = (uint64_t)blockIdx.x * TS_NOM;
+  const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
+  const uint32_t L = (uint32_t)(we - wb);
+  uint64_t kreg[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t x = (uint32_t)it * 256u + tid;
+    const uint64_t a = wb + x;
+    kreg[it] = x < L ? key[a] : ~0ull;
+    gk[x] = (uint32_t)(kreg[it] >> 20);
+  }
+  const uint32_t gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t x = (uint32_t)it * 256u + tid;
+    const bool head = x < L && (wb + x == 0 || gk[x] != (x ? gk[x - 1] : gprev));
+    const uint64_t m = __ballot(head);
+    if (lane == 0) hm[it * 4 + w] = m;
+  }
+  __syncthreads();
+  if (w == 0) {      // per mask word: last head strictly before the word, first head strictly after it
+    const uint64_t m = hm[lane];
+    const int lastin = m ? lane * 64 + 63 - (int)__builtin_clzll(m) : -1;
+    const int firstin = m ? lane * 64 + (int)__builtin_ctzll(m) : (int)TS_WIN + 1;
+    int il = wave_incl_max(lastin);
+    int el = __shfl_up(il, 1, 64); if (lane == 0) el = -1;
+    // suffix min of firstin: max-scan on the reversed lane order of the negated value
+    int neg = -firstin;
+    int rv = __shfl(neg, 63 - lane, 64);
+    int ir = wave_incl_max(rv);
+    int er = __shfl_up(ir, 1, 64); if (lane == 0) er = -((int)TS_WIN + 1);
+    const int en = -__shfl(er, 63 - lane, 64);
+    wlast[lane] = el; wnext[lane] = en;
+  }
+  __syncthreads();
+  int any_medium = 0;
+  uint32_t hx16[16];          // head slot (low 16 bits) | group size (high 16 bits) of owned slots, 0xFFFFFFFF otherwise
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t x = (uint32_t)it * 256u + tid;
+    const int wi = it * 4 + w;
+    const uint64_t m = hm[wi];
+    const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const uint64_t gt = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    int hx = (m & le) ? wi * 64 + 63 - (int)__builtin_clzll(m & le) : wlast[wi];            // head slot of my group (-1: before the window)
+    int nx = (m & gt) ? wi * 64 + (int)__builtin_ctzll(m & gt) : wnext[wi];                  // next head after me
+    if (nx > (int)L) nx = (we == A) ? (int)L : (int)TS_WIN + 1;                              // the array end closes the last group
+    const bool valid = x < L;
+    const bool small = valid && hx >= 0 && nx <= (int)L && (uint32_t)(nx - hx) <= TS_MAXGRP;
+    const bool owned = small && (uint32_t)hx < TS_NOM;
+    if (owned && dflag) dflag[wb + x] = 0;
+    const uint64_t mo = __ballot(owned);
+    if (lane == 0) om[wi] = mo;
+    hx16[it] = owned ? ((uint32_t)hx | ((uint32_t)(nx - hx) << 16)) : 0xFFFFFFFFu;
+    any_medium |= (owned && (nx - hx) > (int)TS_TINY) ? 1 : 0;
+    const uint64_t k = kreg[it];
+    const uint64_t v = valid ? (uint64_t)val[wb + x] : 0ull;
+    sk[x] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
+                  : (((uint64_t)x << 52) | (0xFFFFFull << 32) | v);
+  }
+  if (!__syncthreads_or(any_medium)) {
+    // every owned group has <= TS_TINY members: rank each member inside its group by counting
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const bool own = hx16[it] != 0xFFFFFFFFu;
+      const uint32_t x = (uint32_t)it * 256u + tid;
+      const uint32_t hx = own ? (hx16[it] & 0xFFFFu) : 0u, g = own ? (hx16[it] >> 16) : 0u;
+      const uint32_t gmax = wave_max(g);
+      if (gmax == 0) continue;
+      const uint64_t mine = sk[x];
+      uint32_t rank = 0;
+      for (uint32_t d = 0; d < gmax; d++) rank += (d < g && sk[hx + d] < mine) ? 1u : 0u;
+      if (own) {
+        key[wb + hx + rank] = ((uint64_t)gk[x] << 20) | ((mine >> 32) & 0xFFFFFull);
+        val[wb + hx + rank] = (uint32_t)mine;
+      }
+    }
+    return;
+  }
+  // bitonic sort of the 4096 window slots
+  for (uint32_t kk = 2; kk <= TS_WIN; kk <<= 1) {
+    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const uint32_t t = (uint32_t)it * 256u + tid;
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint32_t l = i | j;
+        const uint64_t a = sk[i], b = sk[l];
+        const bool up = (i & kk) == 0;
+        if ((a > b) == up) { sk[i] = b; sk[l] = a; }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t x = (uint32_t)it * 256u + tid;
+    if ((om[it * 4 + w] >> lane) & 1ull) {
+      const uint64_t e = sk[x];
+      key[wb + x] = ((uint64_t)gk[x] << 20) | ((e >> 32) & 0xFFFFFull);
+      val[wb + x] = (uint32_t)e;
+    }
+  }
+}
+// single workgroup: exclusive scan of n counters in place, total -> *total
+__global__ __launch_bounds__(1024) void scan_u32_single(uint32_t* __restrict__ arr, uint32_t n, uint32_t* __restrict__ total) {
+  __shared__ uint32_t sm[16];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    uint32_t v = i < n ? arr[i] : 0u, tot;
+    const uint32_t ex = block_excl_sum<1024>(v, sm, tot);
+    if (i < n) arr[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(256) void bwt_defer_count(uint32_t A, const uint8_t* __restrict__ dflag, uint32_t* __restrict__ tcount) {
+  __shared__ uint32_t sm[4];
+  const uint64_t a0 = (uint64_t)blockIdx.x * TS_GT + (uint32_t)threadIdx.x * 8u;
+  uint32_t cnt = 0;
+  if (a0 + 8 <= A) { const uint64_t f = *(const uint64_t*)(dflag + a0); cnt = (uint32_t)__builtin_popcountll(f & 0x0101010101010101ull); }
+  else for (int j = 0; j < 8; j++) if (a0 + j < A && dflag[a0 + j]) cnt++;
+  cnt = block_sum<256>(cnt, sm);
+  if (threadIdx.x == 0) tcount[blockIdx.x] = cnt;
+}
+__global__ __launch_bounds__(256) void bwt_defer_gather(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t A,
+                                                        const uint8_t* __restrict__ dflag, const uint32_t* __restrict__ tcount,
+                                                        uint64_t* __restrict__ dk, uint32_t* __restrict__ dv, uint32_t* __restrict__ dpos) {
+  __shared__ uint32_t sm[4];
+  const uint64_t a0 = (uint64_t)blockIdx.x * TS_GT + (uint32_t)threadIdx.x * 8u;
+  uint32_t f = 0, cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) if (a0 + j < A && dflag[a0 + j]) { f |= 1u << j; cnt++; }
+  uint32_t tot;
+  uint32_t o = tcount[blockIdx.x] + block_excl_sum<256>(cnt, sm, tot);
+#pragma unroll
+  for (int j = 0; j < 8; j++) if ((f >> j) & 1u) { dk[o] = key[a0 + j]; dv[o] = val[a0 + j]; dpos[o] = (uint32_t)(a0 + j); o++; }
+}
+__global__ __launch_bounds__(256) void bwt_defer_scatter(uint32_t D, const uint64_t* __restrict__ dk, const uint32_t* __restrict__ dv,
+                                                         const uint32_t* __restrict__ dpos, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < D; j += (uint64_t)gridDim.x * 256) { const uint32_t a = dpos[j]; key[a] = dk[j]; val[a] = dv[j]; }
+}
+
 __global__ __launch_bounds__(256) void bwt_flush_active(uint32_t A, const uint32_t* __restrict__ val, const uint32_t* __restrict__ pos,
                                                         uint32_t* __restrict__ SA) {
   for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < A; a += (uint64_t)gridDim.x * 256) SA[pos[a]] = val[a];
@@ -581,6 +744,42 @@ int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
 }
 template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, int, int);
 
+// One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.
+// Works in place on (key[c], val[c]); only the whole-array fallback flips c.
+static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt) {
+  static const bool no_tiles = getenv("CJS_NO_TILE_SORT") != nullptr;
+  if (no_tiles || A < 2 * TS_WIN) return radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, lt);
+  const uint32_t Tt = (A + TS_NOM - 1) / TS_NOM, Tg = (A + TS_GT - 1) / TS_GT;
+  uint8_t* dflag = (uint8_t*)w.gord;                    // gord is dead between bwt_gather_keys and bwt_apply
+  uint32_t* tcount = w.tile_cnt;                        // 3*cap/4096 entries >= cap/2048
+  if (w.no_large_groups) {                              // groups only ever split: once none exceeds TS_MAXGRP, none will
+    hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, w.key[c], w.val[c], A, (uint8_t*)nullptr);
+    CJS_HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  CJS_HIP_TRY(hipMemsetAsync(dflag, 1, A, s));
+  hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, w.key[c], w.val[c], A, dflag);
+  hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, tcount);
+  hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2);
+  CJS_HIP_TRY(hipMemcpyAsync(w.h_counters + 2, w.counters + 2, 4, hipMemcpyDeviceToHost, s));
+  CJS_HIP_TRY(hipStreamSynchronize(s));
+  const uint32_t D = w.h_counters[2];
+  if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt]   tile sort: %u of %u suffixes in groups > %u\n", D, A, TS_MAXGRP);
+  if (D == 0) w.no_large_groups = true;
+  if (D == 0) return 0;
+  if ((size_t)D > w.cap / 2) return radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, lt);
+  uint64_t* dk0 = w.key[1 - c]; uint64_t* dk1 = dk0 + w.cap / 2;
+  uint32_t* dv0 = w.val[1 - c]; uint32_t* dv1 = dv0 + w.cap / 2;
+  uint32_t* dpos = w.pos[1 - pc];
+  hipLaunchKernelGGL(bwt_defer_gather, dim3(Tg), dim3(256), 0, s, w.key[c], w.val[c], A, dflag, tcount, dk0, dv0, dpos);
+  int cur = 0;
+  CJS_TRY((radix_passes<uint64_t>(s, w, dk0, dv0, dk1, dv1, cur, D, 0, bits, lt)));
+  hipLaunchKernelGGL(bwt_defer_scatter, dim3((D + 255) / 256 < 8192u ? (D + 255) / 256 : 8192u), dim3(256), 0, s, D, cur ? dk1 : dk0, cur ? dv1 : dv0, dpos,
+                     w.key[c], w.val[c]);
+  CJS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t stride, uint32_t n_last,
             bool cyclic, uint8_t* d_U, uint32_t* d_pidx, cjs_stats* stats) {
   if (nb == 0) return 0;
@@ -601,9 +800,11 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   if (nsym > 7) nsym = 7;
   hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0], w.pos[0]);
   uint32_t A = M, h = (uint32_t)nsym, rounds = 0;
+  w.no_large_groups = false;
   int bits = nsym * sym_bits + blk_bits;
   for (;;) {
-    CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
+    if (rounds == 0) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
+    else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters);

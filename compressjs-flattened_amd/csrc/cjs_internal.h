@@ -64,6 +64,7 @@ struct BwtWork {
   uint32_t* counters = nullptr;  // 16: [0] survivors [1] groups [8] tile ticket [9] look-back error
   uint32_t* ghist = nullptr;     // [8][256] digit histograms + [8][256] their exclusive scans (onesweep passes)
   uint32_t* h_counters = nullptr;  // pinned host mirror
+  bool no_large_groups = false;    // per bwt_run: no unresolved group exceeds the tile sorter's limit any more
   static size_t bytes_needed(size_t cap);
   int carve(Arena& a, size_t cap);
 };
