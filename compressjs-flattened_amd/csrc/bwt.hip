@@ -457,23 +457,62 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
 // passes (compact -> sort -> scatter back).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t TS_WIN = 4096, TS_MAXGRP = 1024, TS_NOM = TS_WIN - TS_MAXGRP, TS_TINY = 64, TS_GT = 2048;
+
+// --- register-resident bitonic network over 4096 elements, 256 threads x 16 ---
+// The 12 index bits are split in three nibbles; a thread holds the 16 elements that differ in ONE nibble
+// (layout Z: bits 0-3, Y: bits 4-7, X: bits 8-11), so the compare-exchange steps on that nibble's bits stay in
+// registers; changing the nibble is a transposition through LDS.  LDS slots are swizzled (ts_phi) so that all
+// three access patterns are bank-conflict free.
+__device__ __forceinline__ void ts_ce(uint64_t& a, uint64_t& b, bool up) {
+  const bool sw = (a > b) == up;
+  const uint64_t x = sw ? b : a, y = sw ? a : b;
+  a = x; b = y;
+}
+// compare-exchange steps of merge phase 2^M on local bit positions PHI..0; BASE = index bit of local bit 0,
+// tb = element index with the local nibble cleared
+template <int BASE, int M, int PHI>
+__device__ __forceinline__ void ts_steps(uint64_t (&r)[16], uint32_t tb) {
+#pragma unroll
+  for (int p = PHI; p >= 0; --p) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      if (e & (1 << p)) continue;
+      const uint32_t i = tb | ((uint32_t)e << BASE);
+      const bool up = ((i >> M) & 1u) == 0u;
+      ts_ce(r[e], r[e | (1 << p)], up);
+    }
+  }
+}
+// ts_phi(i) = (hi<<8) | ((mid ^ (hi>>1))<<4) | (lo ^ mid ^ hi); per layout it is (thread constant) ^ (compile-time constant of e)
+template <int LAYOUT> __device__ __forceinline__ constexpr uint32_t ts_ke(uint32_t e) {
+  return LAYOUT == 0 ? e : LAYOUT == 1 ? (e << 4 | e) : ((e << 8) | ((e >> 1) << 4) | e);
+}
+template <int LAYOUT> __device__ __forceinline__ void ts_store(uint64_t* sk, const uint64_t (&r)[16], uint32_t c) {
+#pragma unroll
+  for (int e = 0; e < 16; e++) sk[c ^ ts_ke<LAYOUT>(e)] = r[e];
+}
+template <int LAYOUT> __device__ __forceinline__ void ts_load(const uint64_t* sk, uint64_t (&r)[16], uint32_t c) {
+#pragma unroll
+  for (int e = 0; e < 16; e++) r[e] = sk[c ^ ts_ke<LAYOUT>(e)];
+}
+#define TS_XPOSE(FROM, TO, CF, CT) do { __syncthreads(); ts_store<FROM>(sk, r, CF); __syncthreads(); ts_load<TO>(sk, r, CT); } while (0)
+
 __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
                                                      uint8_t* __restrict__ dflag) {
   __shared__ uint64_t sk[TS_WIN];
-  __shared__ uint32_t gk[TS_WIN];
-  __shared__ uint64_t hm[64], om[64];            // head mask, owned(+sortable) mask
+  __shared__ uint64_t hm[64];                    // head mask of the window
   __shared__ int32_t wlast[64], wnext[64];       // last head before word / first head after word (window slot, -1 / TS_WIN+1 = none)
+  uint32_t* gk = (uint32_t*)sk;                  // group ordinals of the window slots (only until the heads are known)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint64_t wb = (uint64_t)blockIdx.x * TS_NOM;
   const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
   const uint32_t L = (uint32_t)(we - wb);
-  uint64_t kreg[16];
+  uint64_t r[16];
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t x = (uint32_t)it * 256u + tid;
-    const uint64_t a = wb + x;
-    kreg[it] = x < L ? key[a] : ~0ull;
-    gk[x] = (uint32_t)(kreg[it] >> 20);
+    r[it] = x < L ? key[wb + x] : ~0ull;
+    gk[x] = (uint32_t)(r[it] >> 20);
   }
   const uint32_t gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
   __syncthreads();
@@ -502,6 +541,7 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
   __syncthreads();
   int any_medium = 0;
   uint32_t hx16[16];          // head slot (low 16 bits) | group size (high 16 bits) of owned slots, 0xFFFFFFFF otherwise
+  uint32_t go[16];            // group ordinal of slot it*256+tid
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t x = (uint32_t)it * 256u + tid;
@@ -516,56 +556,55 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     const bool small = valid && hx >= 0 && nx <= (int)L && (uint32_t)(nx - hx) <= TS_MAXGRP;
     const bool owned = small && (uint32_t)hx < TS_NOM;
     if (owned && dflag) dflag[wb + x] = 0;
-    const uint64_t mo = __ballot(owned);
-    if (lane == 0) om[wi] = mo;
     hx16[it] = owned ? ((uint32_t)hx | ((uint32_t)(nx - hx) << 16)) : 0xFFFFFFFFu;
     any_medium |= (owned && (nx - hx) > (int)TS_TINY) ? 1 : 0;
-    const uint64_t k = kreg[it];
-    const uint64_t v = valid ? (uint64_t)val[wb + x] : 0ull;
-    sk[x] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
-                  : (((uint64_t)x << 52) | (0xFFFFFull << 32) | v);
+    const uint64_t k = r[it];
+    go[it] = (uint32_t)(k >> 20);
+    const uint64_t v = owned ? (uint64_t)val[wb + x] : 0ull;
+    r[it] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
+                  : (((uint64_t)x << 52) | (0xFFFFFull << 32));
   }
   if (!__syncthreads_or(any_medium)) {
     // every owned group has <= TS_TINY members: rank each member inside its group by counting
 #pragma unroll
+    for (int it = 0; it < 16; it++) sk[(uint32_t)it * 256u + tid] = r[it];
+    __syncthreads();
+#pragma unroll
     for (int it = 0; it < 16; it++) {
       const bool own = hx16[it] != 0xFFFFFFFFu;
-      const uint32_t x = (uint32_t)it * 256u + tid;
       const uint32_t hx = own ? (hx16[it] & 0xFFFFu) : 0u, g = own ? (hx16[it] >> 16) : 0u;
       const uint32_t gmax = wave_max(g);
       if (gmax == 0) continue;
-      const uint64_t mine = sk[x];
+      const uint64_t mine = r[it];
       uint32_t rank = 0;
       for (uint32_t d = 0; d < gmax; d++) rank += (d < g && sk[hx + d] < mine) ? 1u : 0u;
       if (own) {
-        key[wb + hx + rank] = ((uint64_t)gk[x] << 20) | ((mine >> 32) & 0xFFFFFull);
+        key[wb + hx + rank] = ((uint64_t)go[it] << 20) | ((mine >> 32) & 0xFFFFFull);
         val[wb + hx + rank] = (uint32_t)mine;
       }
     }
     return;
   }
-  // bitonic sort of the 4096 window slots
-  for (uint32_t kk = 2; kk <= TS_WIN; kk <<= 1) {
-    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
-        const uint32_t t = (uint32_t)it * 256u + tid;
-        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const uint32_t l = i | j;
-        const uint64_t a = sk[i], b = sk[l];
-        const bool up = (i & kk) == 0;
-        if ((a > b) == up) { sk[i] = b; sk[l] = a; }
-      }
-      __syncthreads();
-    }
-  }
+  // bitonic sort of the window: an element's start position is irrelevant, so register e of thread t starts as
+  // element t*16+e (layout Z) without touching LDS
+  const uint32_t t = (uint32_t)tid, q = t >> 4, l = t & 15;
+  const uint32_t tbZ = t << 4, tbY = (q << 8) | l, tbX = t;
+  const uint32_t cZ = (q << 8) | ((l ^ (q >> 1)) << 4) | ((l ^ q) & 15u);   // ts_phi(t*16) : hi=q mid=l lo=0
+  const uint32_t cY = (q << 8) | ((q >> 1) << 4) | ((l ^ q) & 15u);         // ts_phi(q<<8|l)  : hi=q mid=0 lo=l
+  const uint32_t cX = (q << 4) | ((l ^ q) & 15u);                           // ts_phi(t)       : hi=0 mid=q lo=l
+  ts_steps<0, 1, 0>(r, tbZ); ts_steps<0, 2, 1>(r, tbZ); ts_steps<0, 3, 2>(r, tbZ); ts_steps<0, 4, 3>(r, tbZ);
+#define TS_PHASE_Y(M) TS_XPOSE(0, 1, cZ, cY); ts_steps<4, M, M - 5>(r, tbY); TS_XPOSE(1, 0, cY, cZ); ts_steps<0, M, 3>(r, tbZ)
+#define TS_PHASE_X(M) TS_XPOSE(0, 2, cZ, cX); ts_steps<8, M, M - 9>(r, tbX); TS_XPOSE(2, 1, cX, cY); ts_steps<4, M, 3>(r, tbY); \
+                      TS_XPOSE(1, 0, cY, cZ); ts_steps<0, M, 3>(r, tbZ)
+  TS_PHASE_Y(5); TS_PHASE_Y(6); TS_PHASE_Y(7); TS_PHASE_Y(8);
+  TS_PHASE_X(9); TS_PHASE_X(10); TS_PHASE_X(11); TS_PHASE_X(12);
+  TS_XPOSE(0, 2, cZ, cX);       // layout X: r[it] is the element of slot it*256+tid
 #pragma unroll
   for (int it = 0; it < 16; it++) {
-    const uint32_t x = (uint32_t)it * 256u + tid;
-    if ((om[it * 4 + w] >> lane) & 1ull) {
-      const uint64_t e = sk[x];
-      key[wb + x] = ((uint64_t)gk[x] << 20) | ((e >> 32) & 0xFFFFFull);
-      val[wb + x] = (uint32_t)e;
+    if (hx16[it] != 0xFFFFFFFFu) {
+      const uint32_t x = (uint32_t)it * 256u + tid;
+      key[wb + x] = ((uint64_t)go[it] << 20) | ((r[it] >> 32) & 0xFFFFFull);
+      val[wb + x] = (uint32_t)r[it];
     }
   }
 }
