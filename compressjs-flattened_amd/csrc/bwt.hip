@@ -458,45 +458,11 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t TS_WIN = 4096, TS_MAXGRP = 1024, TS_NOM = TS_WIN - TS_MAXGRP, TS_TINY = 64, TS_GT = 2048;
 
-// --- register-resident bitonic network over 4096 elements, 256 threads x 16 ---
-// The 12 index bits are split in three nibbles; a thread holds the 16 elements that differ in ONE nibble
-// (layout Z: bits 0-3, Y: bits 4-7, X: bits 8-11), so the compare-exchange steps on that nibble's bits stay in
-// registers; changing the nibble is a transposition through LDS.  LDS slots are swizzled (ts_phi) so that all
-// three access patterns are bank-conflict free.
 __device__ __forceinline__ void ts_ce(uint64_t& a, uint64_t& b, bool up) {
   const bool sw = (a > b) == up;
   const uint64_t x = sw ? b : a, y = sw ? a : b;
   a = x; b = y;
 }
-// compare-exchange steps of merge phase 2^M on local bit positions PHI..0; BASE = index bit of local bit 0,
-// tb = element index with the local nibble cleared
-template <int BASE, int M, int PHI>
-__device__ __forceinline__ void ts_steps(uint64_t (&r)[16], uint32_t tb) {
-#pragma unroll
-  for (int p = PHI; p >= 0; --p) {
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      if (e & (1 << p)) continue;
-      const uint32_t i = tb | ((uint32_t)e << BASE);
-      const bool up = ((i >> M) & 1u) == 0u;
-      ts_ce(r[e], r[e | (1 << p)], up);
-    }
-  }
-}
-// ts_phi(i) = (hi<<8) | ((mid ^ (hi>>1))<<4) | (lo ^ mid ^ hi); per layout it is (thread constant) ^ (compile-time constant of e)
-template <int LAYOUT> __device__ __forceinline__ constexpr uint32_t ts_ke(uint32_t e) {
-  return LAYOUT == 0 ? e : LAYOUT == 1 ? (e << 4 | e) : ((e << 8) | ((e >> 1) << 4) | e);
-}
-template <int LAYOUT> __device__ __forceinline__ void ts_store(uint64_t* sk, const uint64_t (&r)[16], uint32_t c) {
-#pragma unroll
-  for (int e = 0; e < 16; e++) sk[c ^ ts_ke<LAYOUT>(e)] = r[e];
-}
-template <int LAYOUT> __device__ __forceinline__ void ts_load(const uint64_t* sk, uint64_t (&r)[16], uint32_t c) {
-#pragma unroll
-  for (int e = 0; e < 16; e++) r[e] = sk[c ^ ts_ke<LAYOUT>(e)];
-}
-#define TS_XPOSE(FROM, TO, CF, CT) do { __syncthreads(); ts_store<FROM>(sk, r, CF); __syncthreads(); ts_load<TO>(sk, r, CT); } while (0)
-
 __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
                                                      uint8_t* __restrict__ dflag) {
   __shared__ uint64_t sk[TS_WIN];
@@ -539,6 +505,8 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     wlast[lane] = el; wnext[lane] = en;
   }
   __syncthreads();
+  __shared__ uint64_t mm[64];                    // mask of the owned slots in groups of > TS_TINY members
+  __shared__ uint32_t mpre[65];
   int any_medium = 0;
   uint32_t hx16[16];          // head slot (low 16 bits) | group size (high 16 bits) of owned slots, 0xFFFFFFFF otherwise
   uint32_t go[16];            // group ordinal of slot it*256+tid
@@ -555,56 +523,93 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     const bool valid = x < L;
     const bool small = valid && hx >= 0 && nx <= (int)L && (uint32_t)(nx - hx) <= TS_MAXGRP;
     const bool owned = small && (uint32_t)hx < TS_NOM;
+    const bool medium = owned && (nx - hx) > (int)TS_TINY;
     if (owned && dflag) dflag[wb + x] = 0;
     hx16[it] = owned ? ((uint32_t)hx | ((uint32_t)(nx - hx) << 16)) : 0xFFFFFFFFu;
-    any_medium |= (owned && (nx - hx) > (int)TS_TINY) ? 1 : 0;
+    const uint64_t mb = __ballot(medium);
+    if (lane == 0) mm[wi] = mb;
+    any_medium |= medium ? 1 : 0;
     const uint64_t k = r[it];
     go[it] = (uint32_t)(k >> 20);
     const uint64_t v = owned ? (uint64_t)val[wb + x] : 0ull;
     r[it] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
                   : (((uint64_t)x << 52) | (0xFFFFFull << 32));
   }
-  if (!__syncthreads_or(any_medium)) {
-    // every owned group has <= TS_TINY members: rank each member inside its group by counting
+  __syncthreads();            // gk (aliasing sk) is dead from here
+  // groups of <= TS_TINY members: every member counts the smaller members of its group
 #pragma unroll
-    for (int it = 0; it < 16; it++) sk[(uint32_t)it * 256u + tid] = r[it];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const bool own = hx16[it] != 0xFFFFFFFFu;
-      const uint32_t hx = own ? (hx16[it] & 0xFFFFu) : 0u, g = own ? (hx16[it] >> 16) : 0u;
-      const uint32_t gmax = wave_max(g);
-      if (gmax == 0) continue;
-      const uint64_t mine = r[it];
-      uint32_t rank = 0;
-      for (uint32_t d = 0; d < gmax; d++) rank += (d < g && sk[hx + d] < mine) ? 1u : 0u;
-      if (own) {
-        key[wb + hx + rank] = ((uint64_t)go[it] << 20) | ((mine >> 32) & 0xFFFFFull);
-        val[wb + hx + rank] = (uint32_t)mine;
-      }
-    }
-    return;
-  }
-  // bitonic sort of the window: an element's start position is irrelevant, so register e of thread t starts as
-  // element t*16+e (layout Z) without touching LDS
-  const uint32_t t = (uint32_t)tid, q = t >> 4, l = t & 15;
-  const uint32_t tbZ = t << 4, tbY = (q << 8) | l, tbX = t;
-  const uint32_t cZ = (q << 8) | ((l ^ (q >> 1)) << 4) | ((l ^ q) & 15u);   // ts_phi(t*16) : hi=q mid=l lo=0
-  const uint32_t cY = (q << 8) | ((q >> 1) << 4) | ((l ^ q) & 15u);         // ts_phi(q<<8|l)  : hi=q mid=0 lo=l
-  const uint32_t cX = (q << 4) | ((l ^ q) & 15u);                           // ts_phi(t)       : hi=0 mid=q lo=l
-  ts_steps<0, 1, 0>(r, tbZ); ts_steps<0, 2, 1>(r, tbZ); ts_steps<0, 3, 2>(r, tbZ); ts_steps<0, 4, 3>(r, tbZ);
-#define TS_PHASE_Y(M) TS_XPOSE(0, 1, cZ, cY); ts_steps<4, M, M - 5>(r, tbY); TS_XPOSE(1, 0, cY, cZ); ts_steps<0, M, 3>(r, tbZ)
-#define TS_PHASE_X(M) TS_XPOSE(0, 2, cZ, cX); ts_steps<8, M, M - 9>(r, tbX); TS_XPOSE(2, 1, cX, cY); ts_steps<4, M, 3>(r, tbY); \
-                      TS_XPOSE(1, 0, cY, cZ); ts_steps<0, M, 3>(r, tbZ)
-  TS_PHASE_Y(5); TS_PHASE_Y(6); TS_PHASE_Y(7); TS_PHASE_Y(8);
-  TS_PHASE_X(9); TS_PHASE_X(10); TS_PHASE_X(11); TS_PHASE_X(12);
-  TS_XPOSE(0, 2, cZ, cX);       // layout X: r[it] is the element of slot it*256+tid
+  for (int it = 0; it < 16; it++) sk[(uint32_t)it * 256u + tid] = r[it];
+  any_medium = __syncthreads_or(any_medium);
 #pragma unroll
   for (int it = 0; it < 16; it++) {
-    if (hx16[it] != 0xFFFFFFFFu) {
+    const bool own = hx16[it] != 0xFFFFFFFFu && (hx16[it] >> 16) <= TS_TINY;
+    const uint32_t hx = own ? (hx16[it] & 0xFFFFu) : 0u, g = own ? (hx16[it] >> 16) : 0u;
+    const uint32_t gmax = wave_max(g);
+    if (gmax == 0) continue;
+    const uint64_t mine = r[it];
+    uint32_t rank = 0;
+    for (uint32_t d = 0; d < gmax; d++) rank += (d < g && sk[hx + d] < mine) ? 1u : 0u;
+    if (own) {
+      key[wb + hx + rank] = ((uint64_t)go[it] << 20) | ((mine >> 32) & 0xFFFFFull);
+      val[wb + hx + rank] = (uint32_t)mine;
+    }
+  }
+  if (!any_medium) return;
+  // larger groups: compact their members (the order of slots is kept), bitonic-sort the compacted array on
+  // (head slot, rank key, suffix), and hand the c-th element to the c-th compacted slot
+  if (w == 0) {
+    const uint32_t pc = (uint32_t)__builtin_popcountll(mm[lane]);
+    const uint32_t inc = wave_incl_sum(pc);
+    mpre[lane] = inc - pc;
+    if (lane == 63) mpre[64] = inc;
+  }
+  __syncthreads();            // also: all counting reads of sk are done
+  const uint32_t Mt = mpre[64];
+  uint32_t P = 2;
+  while (P < Mt) P <<= 1;
+  uint32_t cix[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const int wi = it * 4 + w;
+    const uint64_t mb = mm[wi];
+    const bool medium = (mb >> lane) & 1ull;
+    cix[it] = medium ? mpre[wi] + (uint32_t)__builtin_popcountll(mb & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+    if (medium) sk[cix[it]] = r[it];
+  }
+  for (uint32_t c = Mt + tid; c < P; c += 256) sk[c] = ~0ull;
+  __syncthreads();
+  for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+    uint32_t j = kk >> 1;
+    if (__builtin_popcount(kk - 1) & 1) {      // odd number of steps in this merge phase: one single step first
+      for (uint32_t t = tid; t < (P >> 1); t += 256) {
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint32_t l = i | j;
+        const uint64_t a = sk[i], b = sk[l];
+        const bool up = (i & kk) == 0;
+        if ((a > b) == up) { sk[i] = b; sk[l] = a; }
+      }
+      __syncthreads();
+      j >>= 1;
+    }
+    for (; j > 0; j >>= 2) {                   // steps j and j/2 in one LDS round trip, 4 elements per thread
+      const uint32_t hj = j >> 1;
+      for (uint32_t t = tid; t < (P >> 2); t += 256) {
+        const uint32_t i0 = ((t & ~(hj - 1)) << 2) | (t & (hj - 1));
+        const bool up = (i0 & kk) == 0;
+        uint64_t e0 = sk[i0], e1 = sk[i0 | hj], e2 = sk[i0 | j], e3 = sk[i0 | j | hj];
+        ts_ce(e0, e2, up); ts_ce(e1, e3, up); ts_ce(e0, e1, up); ts_ce(e2, e3, up);
+        sk[i0] = e0; sk[i0 | hj] = e1; sk[i0 | j] = e2; sk[i0 | j | hj] = e3;
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    if (cix[it] != 0xFFFFFFFFu) {
       const uint32_t x = (uint32_t)it * 256u + tid;
-      key[wb + x] = ((uint64_t)go[it] << 20) | ((r[it] >> 32) & 0xFFFFFull);
-      val[wb + x] = (uint32_t)r[it];
+      const uint64_t e = sk[cix[it]];
+      key[wb + x] = ((uint64_t)go[it] << 20) | ((e >> 32) & 0xFFFFFull);
+      val[wb + x] = (uint32_t)e;
     }
   }
 }
@@ -783,6 +788,9 @@ int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
 }
 template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, int, int);
 
+static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag) {
+  hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
+}
 // One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.
 // Works in place on (key[c], val[c]); only the whole-array fallback flips c.
 static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt) {
@@ -792,12 +800,12 @@ static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int
   uint8_t* dflag = (uint8_t*)w.gord;                    // gord is dead between bwt_gather_keys and bwt_apply
   uint32_t* tcount = w.tile_cnt;                        // 3*cap/4096 entries >= cap/2048
   if (w.no_large_groups) {                              // groups only ever split: once none exceeds TS_MAXGRP, none will
-    hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, w.key[c], w.val[c], A, (uint8_t*)nullptr);
+    launch_tile_sort(s, Tt, w.key[c], w.val[c], A, nullptr);
     CJS_HIP_TRY(hipGetLastError());
     return 0;
   }
   CJS_HIP_TRY(hipMemsetAsync(dflag, 1, A, s));
-  hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, w.key[c], w.val[c], A, dflag);
+  launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag);
   hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, tcount);
   hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2);
   CJS_HIP_TRY(hipMemcpyAsync(w.h_counters + 2, w.counters + 2, 4, hipMemcpyDeviceToHost, s));
