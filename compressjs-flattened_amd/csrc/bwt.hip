@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void rs_onesweep(const K* __restrict__ kin, co
 // ------------------------------------------------------------------------------------------
 // round 0 keys: (block id, first nsym symbols).  cyclic: bytes wrap; sentinel: 9-bit symbols, 0 = past the end
 __global__ __launch_bounds__(256) void bwt_init_keys(const uint8_t* __restrict__ T, Geom g, int cyclic, int nsym, uint32_t M,
-                                                     uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ pos) {
+                                                     uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
   for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < M; a += (uint64_t)gridDim.x * 256) {
     const uint32_t blk = (uint32_t)(a / g.stride), i = (uint32_t)(a - (uint64_t)blk * g.stride), n = blk_len(g, blk);
     const uint8_t* t = T + (size_t)blk * g.stride;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void bwt_init_keys(const uint8_t* __restrict__
       for (int j = 0; j < nsym; j++) { const uint32_t x = i + j; k = (k << 9) | (x < n ? (uint32_t)t[x] + 1u : 0u); }
       k |= (uint64_t)blk << (9 * nsym);
     }
-    key[a] = k; val[a] = i; pos[a] = (uint32_t)a;
+    key[a] = k; val[a] = i;                // slot a of round 1 is sorted position a: no pos[] yet
   }
 }
 
@@ -371,13 +371,14 @@ __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ ti
 // regroup: new ranks -> R (scattered 4-byte stores), singletons -> SA, survivors compacted into the next
 // active arrays.  Fully lane-striped: the per-element prefix quantities come from 4096-bit masks
 // (wave ballots) + a 64-word scan, so every global access of a wave touches consecutive addresses.
+template <bool FIRST>      // FIRST: round 1 - slot a is sorted position a, and there is no previous grouping
 __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                  const uint32_t* __restrict__ pos, uint32_t A, Geom g,
                                                  const uint32_t* __restrict__ tile_cnt, uint32_t T,
                                                  uint32_t* __restrict__ R, uint32_t* __restrict__ SA,
                                                  uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord) {
   __shared__ uint64_t sk[RS_TILE + 2];
-  __shared__ uint64_t m_nh[64], m_sg[64];
+  __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
   const uint32_t tile = xcd_tile(blockIdx.x, T);
   if (tile >= T) return;
@@ -404,6 +405,11 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
     const bool nx = a + 1 == A || sk[e + 2] != k;
     const uint64_t mnh = __ballot(nh), msg = __ballot(nh && nx);
     if (lane == 0) { m_nh[it * 4 + w] = mnh; m_sg[it * 4 + w] = msg; }
+    if (!FIRST) {
+      const bool oh = ok && (a == 0 || (sk[e] >> 20) != (k >> 20));      // head of a group of the previous round
+      const uint64_t moh = __ballot(oh);
+      if (lane == 0) m_oh[it * 4 + w] = moh;
+    }
   }
   __syncthreads();
   if (w == 0) {                          // 64 mask words, one per lane
@@ -430,12 +436,19 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
       const uint64_t mh = m_nh[wi], ms = m_sg[wi];
       const uint64_t hm = mh & le;
       uint32_t head_a;                    // global index of the governing group head
-      if (hm) head_a = (uint32_t)base + (uint32_t)wi * 64u + 63u - (uint32_t)__builtin_clzll(hm);
-      else head_a = wp_head[wi] ? (uint32_t)base + wp_head[wi] - 1u : carry - 1u;
-      const uint32_t p = pos[a], vv = val[a];
+      bool keeps_rank = false;            // the head also led the group of the previous round: R already holds this rank
+      if (hm || wp_head[wi]) {
+        const uint32_t hrel = hm ? (uint32_t)wi * 64u + 63u - (uint32_t)__builtin_clzll(hm) : wp_head[wi] - 1u;
+        head_a = (uint32_t)base + hrel;
+        if (!FIRST) keeps_rank = (m_oh[hrel >> 6] >> (hrel & 63u)) & 1ull;
+      } else {
+        head_a = carry - 1u;
+        if (!FIRST) keeps_rank = head_a == 0 || (key[head_a] >> 20) != (key[head_a - 1] >> 20);
+      }
+      const uint32_t p = FIRST ? (uint32_t)a : pos[a], vv = val[a];
       const uint32_t blk = p / g.stride;
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
-      R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
+      if (!keeps_rank) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
       if ((ms >> lane) & 1ull) SA[p] = vv;
       else {
         const uint32_t so = sbase + wp_s[wi] + (uint32_t)__popcll(~ms & lt);
@@ -845,7 +858,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   const int blk_bits = bits_for(nb - 1), sym_bits = cyclic ? 8 : 9;
   int nsym = (64 - blk_bits) / sym_bits;
   if (nsym > 7) nsym = 7;
-  hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0], w.pos[0]);
+  hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0]);
   uint32_t A = M, h = (uint32_t)nsym, rounds = 0;
   w.no_large_groups = false;
   int bits = nsym * sym_bits + blk_bits;
@@ -855,8 +868,10 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters);
-    hipLaunchKernelGGL(bwt_apply, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                       w.val[1 - c], w.pos[1 - pc], w.gord);
+    if (rounds == 0) hipLaunchKernelGGL(bwt_apply<true>, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+                                        w.val[1 - c], w.pos[1 - pc], w.gord);
+    else hipLaunchKernelGGL(bwt_apply<false>, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+                            w.val[1 - c], w.pos[1 - pc], w.gord);
     CJS_HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters, 40, hipMemcpyDeviceToHost, s));
     CJS_HIP_TRY(hipStreamSynchronize(s));
     rounds++;
