@@ -21,6 +21,8 @@ struct cjs_ctx {
   uint32_t cap = 0;
   size_t max_input = 0, max_blocks = 0, range_blocks = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;            // block CRCs run here, beside the suffix sort
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   Arena arena;
   Rle1Work rle;
   BwtWork bwt;
@@ -70,6 +72,9 @@ extern "C" int cjs_ctx_create_sharded(cjs_ctx** out, int device, size_t max_inpu
     if (!c->d_pidx) rc = CJS_E_OUT_OF_MEMORY;
   }
   if (!rc && hipStreamCreate(&c->stream) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && !getenv("CJS_NO_SIDE_STREAM") && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipHostMalloc((void**)&c->h_scalars, 256) != hipSuccess) rc = CJS_E_HIP;
   if (!rc) rc = c->timer.init(c->stream);
   if (rc) { cjs_ctx_destroy(c); return rc; }
@@ -81,6 +86,9 @@ extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   c->timer.destroy();
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->bwt.h_counters) (void)hipHostFree(c->bwt.h_counters);
@@ -115,7 +123,7 @@ static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, l
     n_last = ((uint32_t*)c->h_scalars)[0];
   }
   // all per-block buffers below are indexed relative to `first`; only rle.block_len / block_crc are absolute
-  CJS_TRY(rle1_finish(s, c->rle, d_in, n, f, cnt, c->d_blocks));
+  CJS_TRY(rle1_finish(s, c->rle, d_in, n, f, cnt, c->d_blocks, c->side, c->ev_fork, c->ev_join));
   if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_rle1 = c->timer.stop(); }
   if (cnt) {
     if (st) c->timer.start();
@@ -127,6 +135,7 @@ static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, l
     if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_huff = c->timer.stop(); }
   }
   if (st) c->timer.start();
+  if (cnt && n && c->side) CJS_HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));      // block CRCs (side stream) before the headers are packed
   CJS_HIP_TRY(hipMemsetAsync(d_out, 0, out_cap & ~(size_t)3, s));
   const uint64_t start_bit = framed ? 32 : 0;
   {  // output size check before any packing: sum of the block bit lengths (small D2H)

@@ -436,7 +436,42 @@ __global__ __launch_bounds__(256) void rle_materialize(const uint8_t* __restrict
 }
 
 // ---- CRC-32 (bzip2: MSB-first, poly 0x04c11db7, init ~0, final ~) of input [s,e) per block
-__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b) {        // a*b mod P, bit k = x^k
+// The CRC register after a string is linear in the string: CRC0(A|B) = CRC0(A) * x^(8|B|) + CRC0(B) in GF(2)[x]/P
+// (CRC0 = zero initial value).  Every thread takes 64 bytes, multiplies its CRC0 by x^(8 * bytes behind its chunk)
+// and the workgroup XORs the products; the powers come from tables built at compile time.
+constexpr uint32_t CRC_SEG = 16384;   // bytes per segment: 256 threads x 64 bytes; segments are 16 KiB-aligned ADDRESS windows
+constexpr uint32_t cgf_mul(uint32_t a, uint32_t b) {                          // a*b mod P, bit k = x^k
+  uint32_t r = 0;
+  for (int i = 31; i >= 0; i--) {
+    r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r;
+}
+struct CrcTables {
+  uint32_t tab[4][256];    // slicing-by-4: tab[k][i] = CRC0 of byte i followed by k zero bytes
+  uint32_t pw64[256];      // x^(8*64*q)
+  uint32_t px[64];         // x^(8*r)
+};
+constexpr CrcTables make_crc_tables() {
+  CrcTables t{};
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i << 24;
+    for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : (c << 1);
+    t.tab[0][i] = c;
+  }
+  for (int k = 1; k < 4; k++)
+    for (uint32_t i = 0; i < 256; i++) { const uint32_t p = t.tab[k - 1][i]; t.tab[k][i] = (p << 8) ^ t.tab[0][p >> 24]; }
+  t.px[0] = 1u;
+  for (int r = 1; r < 64; r++) t.px[r] = cgf_mul(t.px[r - 1], 0x100u);
+  const uint32_t x64 = cgf_mul(t.px[63], 0x100u);
+  t.pw64[0] = 1u;
+  for (int q = 1; q < 256; q++) t.pw64[q] = cgf_mul(t.pw64[q - 1], x64);
+  return t;
+}
+__device__ const CrcTables g_crc_tables = make_crc_tables();
+
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b) {
   uint32_t r = 0;
 #pragma unroll 4
   for (int i = 31; i >= 0; i--) {
@@ -454,74 +489,90 @@ __device__ uint32_t gf_xpow8(uint64_t nbytes) {                              // 
   }
   return result;
 }
-constexpr uint32_t CRC_SEG = 16384;   // bytes per workgroup: 256 threads x 64 bytes
+// x^(8*n) for n < 16384 from the tables
+__device__ __forceinline__ uint32_t gf_xpow8_small(uint32_t n, const uint32_t* pw64, const uint32_t* px) {
+  const uint32_t q = n >> 6, r = n & 63u;
+  return r ? gf_mul(pw64[q], px[r]) : pw64[q];
+}
 
 __global__ __launch_bounds__(256) void rle_crc_partial(const uint8_t* __restrict__ in, const RleBlock* __restrict__ blocks,
                                                        const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
                                                        uint32_t first, uint32_t* __restrict__ seg_crc) {
-  __shared__ uint32_t tab[4][256];     // slicing-by-4: tab[k][i] = CRC of byte i followed by k zero bytes
-  __shared__ uint32_t part[256];
+  __shared__ uint32_t tab[4][256];
+  __shared__ uint32_t pw64[256], px[64];
+  __shared__ uint32_t seg[CRC_SEG / 4 + CRC_SEG / 64];      // dword d of the window lives at d + d/16 (bank-conflict-free 64-byte strides)
+  __shared__ uint32_t part[4];
   const uint32_t k = first + blockIdx.y;
   if (k >= *nblocks_p) return;
   const RleBlock bd = blocks[k];
-  if (bd.s + (uint64_t)blockIdx.x * CRC_SEG >= bd.e) return;
-  {
-    uint32_t c = (uint32_t)threadIdx.x << 24;
-    for (int i = 0; i < 8; i++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : (c << 1);
-    tab[0][threadIdx.x] = c;
-  }
-  __syncthreads();
-  for (int t = 1; t < 4; t++) {
-    const uint32_t p = tab[t - 1][threadIdx.x];
-    tab[t][threadIdx.x] = (p << 8) ^ tab[0][p >> 24];
+  const int tid = threadIdx.x;
+  // absolute byte addresses; windows are aligned in the address space so that every staging load is a 16-byte aligned one
+  const uint64_t A0 = (uint64_t)(uintptr_t)in, S = A0 + bd.s, E = A0 + bd.e;
+  const uint64_t W0 = S & ~(uint64_t)(CRC_SEG - 1);
+  if (W0 + (uint64_t)blockIdx.x * CRC_SEG >= E) return;
+  for (int j = 0; j < 4; j++) tab[j][tid] = g_crc_tables.tab[j][tid];
+  pw64[tid] = g_crc_tables.pw64[tid];
+  if (tid < 64) px[tid] = g_crc_tables.px[tid];
+  for (uint32_t sgi = blockIdx.x; W0 + (uint64_t)sgi * CRC_SEG < E; sgi += gridDim.x) {
+    const uint64_t W = W0 + (uint64_t)sgi * CRC_SEG;
+    const uint64_t lo = W > S ? W : S, hi = W + CRC_SEG < E ? W + CRC_SEG : E;      // bytes of the block in this window
     __syncthreads();
-  }
-  // gridDim.x workgroups per block stride over its 16 KiB segments (a block of plain text has ~55 of them, a block
-  // of one long run up to 2,800)
-  for (uint32_t sgi = blockIdx.x; bd.s + (uint64_t)sgi * CRC_SEG < bd.e; sgi += gridDim.x) {
-    const uint64_t seg_start = bd.s + (uint64_t)sgi * CRC_SEG;
-    const uint64_t a = seg_start + (uint64_t)threadIdx.x * 64;
-    uint64_t bend = a + 64; if (bend > bd.e) bend = bd.e;
-    uint32_t crc = 0;
-    uint64_t p = a;
-    for (; p + 4 <= bend; p += 4) {
-      const uint32_t x = crc ^ (((uint32_t)in[p] << 24) | ((uint32_t)in[p + 1] << 16) | ((uint32_t)in[p + 2] << 8) | (uint32_t)in[p + 3]);
-      crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 0xff] ^ tab[1][(x >> 8) & 0xff] ^ tab[0][x & 0xff];
+    for (int j = 0; j < 4; j++) {
+      const uint32_t c = (uint32_t)j * 256u + tid;                 // 16-byte chunk of the window
+      const uint64_t ca = W + (uint64_t)c * 16;
+      if (ca + 16 > lo && ca < hi) {
+        const uint4 v = *(const uint4*)(uintptr_t)ca;              // may include bytes outside [lo,hi): never used
+        const uint32_t d = c * 4u, o = d + (d >> 4);
+        seg[o] = v.x; seg[o + 1] = v.y; seg[o + 2] = v.z; seg[o + 3] = v.w;
+      }
     }
-    for (; p < bend; p++) crc = (crc << 8) ^ tab[0][((crc >> 24) ^ in[p]) & 0xff];
-    part[threadIdx.x] = crc;
     __syncthreads();
-    // tree combine: node (t, width w) = combine(left part[t], right part[t+w]) where right covers bytes
-    // [a + 64w, a + 128w) clipped to e
-    for (uint32_t wdt = 1; wdt < 256; wdt <<= 1) {
-      if ((threadIdx.x & (2 * wdt - 1)) == 0) {
-        const uint64_t rstart = seg_start + (uint64_t)(threadIdx.x + wdt) * 64;
-        if (rstart < bd.e) {
-          uint64_t rend = rstart + (uint64_t)wdt * 64; if (rend > bd.e) rend = bd.e;
-          part[threadIdx.x] = gf_mul(part[threadIdx.x], gf_xpow8(rend - rstart)) ^ part[threadIdx.x + wdt];
+    const uint64_t ca = W + (uint64_t)tid * 64, cb = ca + 64;
+    const uint64_t a = ca > lo ? ca : lo, b = cb < hi ? cb : hi;
+    uint32_t crc = 0;
+    if (a < b) {
+      const uint32_t o = (uint32_t)tid * 17u;
+      if (b - a == 64) {
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+          const uint32_t x = crc ^ __builtin_bswap32(seg[o + i]);
+          crc = tab[3][x >> 24] ^ tab[2][(x >> 16) & 0xff] ^ tab[1][(x >> 8) & 0xff] ^ tab[0][x & 0xff];
+        }
+      } else {
+        for (uint64_t p = a; p < b; p++) {
+          const uint32_t off = (uint32_t)(p - ca);
+          const uint32_t byte = (seg[o + (off >> 2)] >> (8u * (off & 3u))) & 0xffu;
+          crc = (crc << 8) ^ tab[0][((crc >> 24) ^ byte) & 0xff];
         }
       }
-      __syncthreads();
+      const uint32_t behind = (uint32_t)(hi - b);
+      if (behind) crc = gf_mul(crc, gf_xpow8_small(behind, pw64, px));
     }
-    if (threadIdx.x == 0) seg_crc[(size_t)blockIdx.y * max_segs + sgi] = part[0];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) crc ^= __shfl_xor(crc, m, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = crc;
     __syncthreads();
+    if (tid == 0) seg_crc[(size_t)blockIdx.y * max_segs + sgi] = part[0] ^ part[1] ^ part[2] ^ part[3];
   }
 }
 
 __global__ void rle_crc_final(const RleBlock* __restrict__ blocks, const uint32_t* __restrict__ nblocks_p, uint32_t max_segs,
-                              uint32_t first, uint32_t count, const uint32_t* __restrict__ seg_crc, uint32_t* __restrict__ block_crc) {
+                              uint32_t first, uint32_t count, const uint8_t* __restrict__ in, const uint32_t* __restrict__ seg_crc,
+                              uint32_t* __restrict__ block_crc) {
   const uint32_t rel = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = first + rel;
   if (rel >= count || k >= *nblocks_p) return;
   const RleBlock bd = blocks[k];
   const uint64_t n = bd.e - bd.s;
+  const uint64_t A0 = (uint64_t)(uintptr_t)in, S = A0 + bd.s, E = A0 + bd.e;
+  const uint64_t W0 = S & ~(uint64_t)(CRC_SEG - 1);
+  const uint32_t xfull = gf_mul(g_crc_tables.pw64[255], g_crc_tables.pw64[1]);     // x^(8*16384)
   uint32_t crc = 0;
-  uint64_t done = 0;
-  const uint32_t xfull = gf_xpow8(CRC_SEG);
-  for (uint32_t sgi = 0; done < n; sgi++) {
-    const uint64_t l = n - done < CRC_SEG ? n - done : CRC_SEG;
-    crc = gf_mul(crc, l == CRC_SEG ? xfull : gf_xpow8(l)) ^ seg_crc[(size_t)rel * max_segs + sgi];
-    done += l;
+  for (uint32_t sgi = 0; W0 + (uint64_t)sgi * CRC_SEG < E; sgi++) {
+    const uint64_t W = W0 + (uint64_t)sgi * CRC_SEG;
+    const uint64_t lo = W > S ? W : S, hi = W + CRC_SEG < E ? W + CRC_SEG : E;
+    const uint32_t l = (uint32_t)(hi - lo);
+    crc = gf_mul(crc, l == CRC_SEG ? xfull : gf_xpow8_small(l, g_crc_tables.pw64, g_crc_tables.px)) ^ seg_crc[(size_t)rel * max_segs + sgi];
   }
   crc ^= gf_mul(0xFFFFFFFFu, gf_xpow8(n));     // init = ~0 carried through n bytes
   block_crc[k] = ~crc;
@@ -563,7 +614,7 @@ int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, c
                uint32_t* d_seg_crc, uint32_t* d_crc_out) {
   if (!count) return 0;
   hipLaunchKernelGGL(rle_crc_partial, dim3(64, count), dim3(256), 0, s, d_data, d_blocks, d_nblocks, max_segs, 0u, d_seg_crc);
-  hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, s, d_blocks, d_nblocks, max_segs, 0u, count, d_seg_crc, d_crc_out);
+  hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, s, d_blocks, d_nblocks, max_segs, 0u, count, d_data, d_seg_crc, d_crc_out);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -589,14 +640,24 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32
 }
 
 // Stage 0b: RLE1 bytes (d_blocks, block k at (k-first)*cap) and CRCs (block_crc[k], absolute) of blocks [first, first+count)
-int rle1_finish(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t first, uint32_t count, uint8_t* d_blocks) {
+int rle1_finish(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t first, uint32_t count, uint8_t* d_blocks,
+                hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
   if (N == 0 || count == 0) return 0;
   if (count > w.range_blocks) return CJS_E_INVALID_ARG;
   const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
+  // the block CRCs read only the input and the block table: with a side stream they run beside the suffix sort
+  // (ev_join is recorded at their end; the caller makes the packing stage wait for it)
+  hipStream_t cs = s;
+  if (side) {
+    CJS_HIP_TRY(hipEventRecord(ev_fork, s));
+    CJS_HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+    cs = side;
+  }
   hipLaunchKernelGGL(rle_materialize, dim3(Tn), dim3(256), 0, s, d_in, N, w.cap, w.lb, w.fb, w.gt, w.blocks, w.nblocks, first, count, d_blocks);
-  hipLaunchKernelGGL(rle_crc_partial, dim3(64, count), dim3(256), 0, s, d_in, w.blocks, w.nblocks, w.max_segs, first, w.seg_crc);
-  hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, s, w.blocks, w.nblocks, w.max_segs, first, count, w.seg_crc, w.block_crc);
+  hipLaunchKernelGGL(rle_crc_partial, dim3(64, count), dim3(256), 0, cs, d_in, w.blocks, w.nblocks, w.max_segs, first, w.seg_crc);
+  hipLaunchKernelGGL(rle_crc_final, dim3((count + 63) / 64), dim3(64), 0, cs, w.blocks, w.nblocks, w.max_segs, first, count, d_in, w.seg_crc, w.block_crc);
   CJS_HIP_TRY(hipGetLastError());
+  if (side) CJS_HIP_TRY(hipEventRecord(ev_join, side));
   return 0;
 }
 
