@@ -20,15 +20,21 @@ constexpr int MAXSYM = 258;
 constexpr int MAX_BITS = 20;
 constexpr int GSZ = 50;
 
+// phase clock of workgroup 0 (CJS_DEBUG only): 100 MHz ticks at the marks of huff_block
+__device__ uint64_t g_huff_clk[32];
+#define HB_MARK(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) g_huff_clk[i] = wall_clock64(); } while (0)
+
 // ------------------------------------------------------------------ allocator (lane 0, LDS array)
+// a[] entries below the root are extended parent pointers p or p + len (p < len), so "% len" is one conditional subtract
+__device__ __forceinline__ int ha_mod(int x, int len) { return x >= len ? x - len : x; }
 __device__ int ha_first(const int* a, int len, int i, int nodes_to_move) {          // Bzip2:1135-1156
   const int limit = i;
   int k = len - 2;
-  while (i >= nodes_to_move && (a[i] % len) > limit) { k = i; i -= (limit - i + 1); }
+  while (i >= nodes_to_move && ha_mod(a[i], len) > limit) { k = i; i -= (limit - i + 1); }
   if (i < nodes_to_move - 1) i = nodes_to_move - 1;
   while (k > i + 1) {
     const int mid = (i + k) >> 1;
-    if ((a[mid] % len) > limit) k = mid; else i = mid;
+    if (ha_mod(a[mid], len) > limit) k = mid; else i = mid;
   }
   return k;
 }
@@ -38,21 +44,26 @@ __device__ void ha_alloc(int* a, int len, int maxlen) {                         
   // pass 1: extended parent pointers (Bzip2:1162-1186)
   a[0] += a[1];
   {
+    // the two queue fronts live in registers two deep (H = a[head], Hn = a[head+1], T = a[top], Tn = a[top+1]), so the
+    // LDS reads that refill them overlap the comparisons instead of sitting on the critical path
     int head = 0, top = 2;
+    int H = a[0], Hn = 0;
+    int T = top < len ? a[top] : 0, Tn = top + 1 < len ? a[top + 1] : 0;
     for (int tail = 1; tail < len - 1; tail++) {
       int w;
-      if (top >= len || a[head] < a[top]) { w = a[head]; a[head++] = tail; }
-      else w = a[top++];
-      if (top >= len || (head < tail && a[head] < a[top])) { w += a[head]; a[head++] = tail + len; }
-      else w += a[top++];
+      if (top >= len || H < T) { w = H; a[head++] = tail; H = Hn; if (head + 1 < tail) Hn = a[head + 1]; }
+      else { w = T; top++; T = Tn; if (top + 1 < len) Tn = a[top + 1]; }
+      if (top >= len || (head < tail && H < T)) { w += H; a[head++] = tail + len; H = Hn; if (head + 1 < tail) Hn = a[head + 1]; }
+      else { w += T; top++; T = Tn; if (top + 1 < len) Tn = a[top + 1]; }
       a[tail] = w;
+      if (head == tail) H = w; else if (head + 1 == tail) Hn = w;
     }
   }
   // pass 2: nodes to relocate (Bzip2:1195-1204)
   int reloc = len - 2;
   for (int depth = 1; depth < maxlen - 1 && reloc > 1; depth++) reloc = ha_first(a, len, reloc - 1, 0);
   // pass 3
-  if ((a[0] % len) >= reloc) {                                                      // Bzip2:1211-1226
+  if (ha_mod(a[0], len) >= reloc) {                                                      // Bzip2:1211-1226
     int first = len - 2, next = len - 1;
     for (int depth = 1, avail = 2; avail > 0; depth++) {
       const int last = first;
@@ -85,10 +96,15 @@ __device__ void build_table_wave(const uint32_t* freq, uint8_t* lens, uint32_t* 
   for (int i = lane; i < n; i += 64) key[i] = (freq[i] << 9) | (uint32_t)i;       // Bzip2:1881-1883
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  int rk[5];
-  for (int t = 0, i = lane; t < 5; t++, i += 64) {
-    rk[t] = 0;
-    if (i < n) { const uint32_t ki = key[i]; int r = 0; for (int k = 0; k < n; k++) r += key[k] < ki; rk[t] = r; }
+  int rk[5] = {0, 0, 0, 0, 0};
+  uint32_t ki[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) { const int i = lane + 64 * t; ki[t] = i < n ? key[i] : 0u; }
+#pragma unroll 6
+  for (int k = 0; k < n; k++) {                 // one broadcast read per key, compared with all five of the lane's keys
+    const uint32_t kv = key[k];
+#pragma unroll
+    for (int t = 0; t < 5; t++) rk[t] += kv < ki[t];
   }
   __builtin_amdgcn_wave_barrier();
   for (int t = 0, i = lane; t < 5; t++, i += 64) if (i < n) work[rk[t]] = (int)(freq[i]);   // sortedFreq
@@ -124,35 +140,52 @@ __device__ void assign_selectors(HuffShared& S, uint32_t* __restrict__ stage /* 
     for (int j = 0; j < ng; j++) pk |= (uint64_t)S.lens[j][s] << (10 * j);
     S.packed[s] = pk;
   }
-  __syncthreads();
   const uint32_t* A32 = reinterpret_cast<const uint32_t*>(A);          // A rows are 16-byte aligned (a_stride % 8 == 0)
   const uint32_t ndw = (npos + 1) / 2;
+  constexpr int NPRE = (AS_GROUPS * 25 + 1023) / 1024;                 // 13 dwords per lane and step
+  uint32_t pre[NPRE];                                                  // next step's symbols: loaded while this step is costed
+#pragma unroll
+  for (int j = 0; j < NPRE; j++) { const uint32_t i = (uint32_t)j * 1024u + threadIdx.x; pre[j] = (i < AS_GROUPS * 25 && i < ndw) ? A32[i] : 0u; }
+  const uint32_t half = threadIdx.x & 1u, gl = threadIdx.x >> 1;       // two lanes per group: dwords [0,13) and [13,25)
   for (uint32_t g0 = 0; g0 < nsel; g0 += AS_GROUPS) {
-    const uint32_t dw0 = g0 * 25;
-    for (uint32_t i = threadIdx.x; i < AS_GROUPS * 25; i += 1024) stage[i] = dw0 + i < ndw ? A32[dw0 + i] : 0u;
+    __syncthreads();                                                   // previous step's readers are done (first step: packed[] is complete)
+#pragma unroll
+    for (int j = 0; j < NPRE; j++) { const uint32_t i = (uint32_t)j * 1024u + threadIdx.x; if (i < AS_GROUPS * 25) stage[i] = pre[j]; }
     __syncthreads();
-    const uint32_t g = g0 + threadIdx.x;
-    if (threadIdx.x < AS_GROUPS && g < nsel) {
-      const uint32_t off = g * GSZ, cnt = npos - off < GSZ ? npos - off : GSZ;
-      const uint32_t* my = stage + threadIdx.x * 25;
-      uint64_t acc = 0;
-      for (uint32_t i = 0; i < cnt; i += 2) {
-        const uint32_t w = my[i >> 1];
-        acc += S.packed[w & 0xFFFFu];
-        if (i + 1 < cnt) acc += S.packed[w >> 16];
+    {
+      const uint32_t dw1 = (g0 + AS_GROUPS) * 25;
+#pragma unroll
+      for (int j = 0; j < NPRE; j++) {
+        const uint32_t i = (uint32_t)j * 1024u + threadIdx.x;
+        pre[j] = (g0 + AS_GROUPS < nsel && i < AS_GROUPS * 25 && dw1 + i < ndw) ? A32[dw1 + i] : 0u;
       }
+    }
+    const uint32_t g = g0 + gl;
+    uint64_t acc = 0;
+    if (g < nsel) {
+      const uint32_t off = g * GSZ, cnt = npos - off < GSZ ? npos - off : GSZ;
+      const uint32_t* my = stage + gl * 25;
+      const uint32_t j0 = half ? 13u : 0u, j1 = half ? 25u : 13u;
+      for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t w = my[j];
+        if (2 * j < cnt) acc += S.packed[w & 0xFFFFu];
+        if (2 * j + 1 < cnt) acc += S.packed[w >> 16];
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (g < nsel && half == 0) {
       int best = 0; uint32_t bc = (uint32_t)(acc & 1023u);
 #pragma unroll
       for (int j = 1; j < 6; j++) { const uint32_t cj = (uint32_t)((acc >> (10 * j)) & 1023u); if (j < ng && cj < bc) { best = j; bc = cj; } }
       sel[g] = (uint8_t)best; bcost[g] = (uint16_t)bc;
     }
-    __syncthreads();
   }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride,
                                                    const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
-                                                   const uint32_t* __restrict__ freq_all, const uint8_t* __restrict__ alist_all) {
+                                                   const uint32_t* __restrict__ freq_all, const uint8_t* __restrict__ alist_all, int dbg) {
   __shared__ HuffShared S;
   __shared__ uint32_t stage[AS_GROUPS * 25];
   const uint32_t blk = blockIdx.x;
@@ -166,14 +199,17 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
   const int target = npos >= 2400 ? 6 : npos >= 1200 ? 5 : npos >= 600 ? 4 : npos >= 200 ? 3 : 2;   // Bzip2:2150
   const int w = wave_id();
 
+  HB_MARK(0);
   // initial tables: global frequencies and flat (Bzip2:2155-2157)
   for (int i = threadIdx.x; i < n; i += 1024) { S.freq[0][i] = freq_all[(size_t)blk * 258 + i]; S.freq[1][i] = 1; }
   __syncthreads();
   if (w < 2) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
   __syncthreads();
   int ng = 2;
+  HB_MARK(1);
   while (ng < target) {                                                             // Bzip2:2012-2053
     assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);
+    if (ng == 2) HB_MARK(2);
     if (threadIdx.x < 8) S.counts[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t g = threadIdx.x; g < nsel; g += 1024) atomicAdd(&S.counts[sel[g]], 1u);
@@ -204,17 +240,59 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
       }
       carry += tot;
     }
+    if (ng == 2) HB_MARK(3);
     ng++;
-    for (int i = threadIdx.x; i < 6 * 260; i += 1024) (&S.freq[0][0])[i] = 0;
+    // MTF output is dominated by a few symbols: eight histogram replicas (by lane) in the idle staging buffer keep the
+    // same-address LDS atomics apart; they are summed afterwards
+    for (int i = threadIdx.x; i < 8 * 6 * 260; i += 1024) stage[i] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < npos; i += 1024) atomicAdd(&S.freq[sel[i / GSZ]][A[i]], 1u);   // Bzip2:2043-2048
+    {                                                                               // Bzip2:2043-2048
+      uint32_t* rep = stage + (threadIdx.x & 7u) * (6 * 260);
+      const uint4* A128 = reinterpret_cast<const uint4*>(A);                          // 8 symbols per load, two loads in flight
+      const uint32_t nv = npos / 8;
+      for (uint32_t v = threadIdx.x; v < nv; v += 2048) {
+        const uint32_t v2 = v + 1024;
+        const uint4 x = A128[v];
+        const uint4 y = v2 < nv ? A128[v2] : make_uint4(0, 0, 0, 0);
+        const uint32_t i0 = v * 8, i1 = v2 * 8;
+        const uint32_t ga = i0 / GSZ, gb = (i0 + 7) / GSZ, gc = v2 < nv ? i1 / GSZ : 0u, gd = v2 < nv ? (i1 + 7) / GSZ : 0u;
+        const uint32_t sa = sel[ga], sb = sel[gb], sc = sel[gc], sd = sel[gd];
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t e0 = i0 + 2 * q, e1 = e0 + 1;
+          atomicAdd(&rep[(e0 / GSZ == ga ? sa : sb) * 260 + (xs[q] & 0xFFFFu)], 1u);
+          atomicAdd(&rep[(e1 / GSZ == ga ? sa : sb) * 260 + (xs[q] >> 16)], 1u);
+        }
+        if (v2 < nv) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t e0 = i1 + 2 * q, e1 = e0 + 1;
+            atomicAdd(&rep[(e0 / GSZ == gc ? sc : sd) * 260 + (ys[q] & 0xFFFFu)], 1u);
+            atomicAdd(&rep[(e1 / GSZ == gc ? sc : sd) * 260 + (ys[q] >> 16)], 1u);
+          }
+        }
+      }
+      for (uint32_t i = nv * 8 + threadIdx.x; i < npos; i += 1024) atomicAdd(&rep[sel[i / GSZ] * 260 + A[i]], 1u);
+    }
     __syncthreads();
+    for (int i = threadIdx.x; i < 6 * 260; i += 1024) {
+      uint32_t f = 0;
+#pragma unroll
+      for (int r = 0; r < 8; r++) f += stage[r * (6 * 260) + i];
+      (&S.freq[0][0])[i] = f;
+    }
+    __syncthreads();
+    if (ng == 3) HB_MARK(4);
     if (w < ng) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
     __syncthreads();
+    if (ng == 3) HB_MARK(5);
   }
+  HB_MARK(6);
   assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);                        // Bzip2:2163
   __syncthreads();
 
+  HB_MARK(7);
   // ---- bit accounting
   uint32_t data_bits = 0;
   for (uint32_t g = threadIdx.x; g < nsel; g += 1024) data_bits += bcost[g];
@@ -255,6 +333,7 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
     }
   }
   sel_bits = block_sum<1024>(sel_bits, S.sm);
+  HB_MARK(8);
   uint32_t tab_bits = 0;
   for (int i = threadIdx.x; i < ng * n; i += 1024) {                                // Bzip2:1926-1947
     const int t = i / n, s = i - t * n;
@@ -290,6 +369,7 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
     gcodes[t * MAXSYM + s] = ((const uint32_t*)&S.work[0][0])[t * 32 + l] + r;
     glens[t * MAXSYM + s] = (uint8_t)l;
   }
+  HB_MARK(9);
   if (threadIdx.x == 0) {
     hb.ngroups[blk] = (uint32_t)ng;
     hb.bitlen[blk] = 80u + 25u + 16u + 16u * nranges + 18u + sel_bits + tab_bits + data_bits;
@@ -466,8 +546,17 @@ int HuffWork::carve(Arena& a, size_t max_blocks_, uint32_t stride) {
 int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                     const uint32_t* d_asz, const uint32_t* d_freq, const uint8_t* d_alist) {
   if (nb == 0) return 0;
-  hipLaunchKernelGGL(huff_block, dim3(nb), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_asz, d_freq, d_alist);
+  static const bool dbg = getenv("CJS_DEBUG") != nullptr;
+  hipLaunchKernelGGL(huff_block, dim3(nb), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_asz, d_freq, d_alist, dbg ? 1 : 0);
   CJS_HIP_TRY(hipGetLastError());
+  if (dbg) {
+    uint64_t clk[32];
+    CJS_HIP_TRY(hipStreamSynchronize(s));
+    CJS_HIP_TRY(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_huff_clk), sizeof clk));
+    static const char* names[] = {"init tables", "assign(ng=2)", "median split(ng=2)", "freq count(ng=2->3)", "build tables(ng=3)",
+                                  "rest of refinement", "final assign", "bit accounting: data+selector mtf", "tables+codes"};
+    for (int i = 0; i < 9; i++) fprintf(stderr, "[cjs huff] wg0 %-36s %8.1f us\n", names[i], (double)(clk[i + 1] - clk[i]) / 100.0);
+  }
   return 0;
 }
 
