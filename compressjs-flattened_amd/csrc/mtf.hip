@@ -128,8 +128,15 @@ __global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
   }
 }
 
-// ---- C2: replay each chunk from its start list; one lane per chunk, list in LDS (row stride 260 B)
+// ---- C2: replay each chunk from its start list; one lane per chunk.
+// The first 16 list positions live in four registers (byte k of the 128-bit value = list position k): finding a
+// symbol there is a SWAR zero-byte test and the move-to-front is a byte shift under a mask, no memory access.
+// Positions >= 16 stay in LDS (row stride 260 B, no bank aliasing between lanes) and are only walked for the few
+// heads whose rank is that large.
 constexpr int LROW = 260;
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }   // lowest set bit is exact
+__device__ __forceinline__ uint32_t low_bytes_mask(int nb) { return nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u); }
+constexpr int MTF_RW = 8;                  // list words held in registers (4 positions each)
 __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
   __shared__ uint8_t L[256 * LROW];
   const uint32_t blk = blockIdx.y, H = mb.nheads[blk], asz = mb.asz[blk];
@@ -141,7 +148,14 @@ __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
   uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
   const uint8_t* lst = mb.lists + (size_t)blk * mb.list_stride + (size_t)c * 256;
   uint8_t* my = L + threadIdx.x * LROW;
-  for (uint32_t j = 0; j < asz; j++) my[j] = lst[j];
+  constexpr uint32_t NR = 4 * MTF_RW;      // positions in registers
+  uint32_t l[MTF_RW];
+#pragma unroll
+  for (int k = 0; k < MTF_RW; k += 4) {    // rows of lists[] are 256-byte aligned; bytes >= asz are never matched first
+    const uint4 f = *reinterpret_cast<const uint4*>(lst + 4 * k);
+    l[k] = f.x; l[k + 1] = f.y; l[k + 2] = f.z; l[k + 3] = f.w;
+  }
+  for (uint32_t j = NR; j < asz; j++) my[j] = lst[j];
   const uint32_t h0 = c * MTF_CHUNK, h1 = h0 + MTF_CHUNK < H ? h0 + MTF_CHUNK : H;
   // 16 heads at a time: one 16-byte load of symbols, one 16-byte store of ranks per lane (hsym/hrank rows
   // are 256-byte aligned: h0 is a multiple of 256 and the per-block stride is padded to 16)
@@ -153,16 +167,32 @@ __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
       const uint32_t h = hb + q;
       uint32_t r = 0;
       if (h < h1) {
-        const uint8_t s8 = (uint8_t)(sw[q >> 2] >> (8 * (q & 3)));
-        uint8_t prev = my[0];
-        if (prev != s8) {
-          my[0] = s8;
-          for (r = 1; r < asz; r++) {
+        const uint32_t s8 = (sw[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+        const uint32_t bc = s8 * 0x01010101u;
+        r = NR;
+#pragma unroll
+        for (int k = MTF_RW - 1; k >= 0; k--) {
+          const uint32_t z = zero_bytes(l[k] ^ bc);
+          if (z) r = 4u * (uint32_t)k + ((uint32_t)__builtin_ctz(z) >> 3);
+        }
+        if (r == NR) {
+          uint8_t prev = (uint8_t)(l[MTF_RW - 1] >> 24);      // falls out of the register part
+          for (; r < asz; r++) {
             const uint8_t x = my[r];
             my[r] = prev;
             prev = x;
-            if (x == s8) break;
+            if (x == (uint8_t)s8) break;
           }
+        }
+        // positions 0..min(r,NR-1) shift up by one, the symbol goes to the front
+        const int nb = (int)(r < NR ? r : NR - 1) + 1;
+        uint32_t carry_in = s8;
+#pragma unroll
+        for (int k = 0; k < MTF_RW; k++) {
+          const uint32_t sh = (l[k] << 8) | carry_in;
+          carry_in = l[k] >> 24;
+          const uint32_t m = low_bytes_mask(nb - 4 * k);
+          l[k] = (sh & m) | (l[k] & ~m);
         }
       }
       rw[q >> 2] |= r << (8 * (q & 3));
