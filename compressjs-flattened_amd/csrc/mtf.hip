@@ -136,7 +136,7 @@ __global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
 constexpr int LROW = 260;
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }   // lowest set bit is exact
 __device__ __forceinline__ uint32_t low_bytes_mask(int nb) { return nb <= 0 ? 0u : nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u); }
-constexpr int MTF_RW = 8;                  // list words held in registers (4 positions each)
+constexpr int MTF_RW = 16;                 // list words held in registers (4 positions each)
 __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
   __shared__ uint8_t L[256 * LROW];
   const uint32_t blk = blockIdx.y, H = mb.nheads[blk], asz = mb.asz[blk];
