@@ -18,44 +18,57 @@ namespace cjs {
 
 constexpr int MTF_CHUNK = 256;
 
-// ---- A: used-symbol list + run-head compaction.  One workgroup per block.
-__global__ __launch_bounds__(1024) void mtf_heads(const uint8_t* __restrict__ U, uint32_t stride, const uint32_t* __restrict__ blen,
-                                                  MtfBufs mb) {
+// ---- A: used-symbol list + run-head compaction.  Tiles of 4096 bytes: count -> per-block scan -> write.
+// tcnt[blk * tpb + tile] and the used flags (uflag[blk * 258 + byte], zeroed by the host) alias buffers that
+// are not live yet (segkeys, freq).
+constexpr uint32_t MT_TILE = 4096;
+template <bool WRITE>
+__global__ __launch_bounds__(1024) void mtf_head_tiles(const uint8_t* __restrict__ U, uint32_t stride, const uint32_t* __restrict__ blen,
+                                                       MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb, uint32_t* __restrict__ uflag) {
   __shared__ uint32_t used[256];
   __shared__ uint32_t sm[16];
-  const uint32_t blk = blockIdx.x, n = blen[blk];
+  const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk];
+  const uint32_t base = tile * MT_TILE;
+  if (base >= n) { if (!WRITE && threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = 0; return; }
   const uint8_t* u = U + (size_t)blk * stride;
-  if (threadIdx.x < 256) used[threadIdx.x] = 0;
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += 1024) used[u[i]] = 1;
-  __syncthreads();
-  {
-    uint32_t f = threadIdx.x < 256 ? used[threadIdx.x] : 0u, tot;
-    const uint32_t ex = block_excl_sum<1024>(f, sm, tot);
-    if (f) mb.alist[(size_t)blk * 256 + ex] = (uint8_t)threadIdx.x;
-    if (threadIdx.x == 0) mb.asz[blk] = tot;
-  }
-  uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
-  uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < n; base += 4096) {
-    const uint32_t p0 = base + threadIdx.x * 4;
-    uint8_t c[4]; uint32_t fm = 0, cnt = 0;
-    uint8_t prev = (p0 > 0 && p0 - 1 < n) ? u[p0 - 1] : 0;
+  if (!WRITE) { if (threadIdx.x < 256) used[threadIdx.x] = 0; __syncthreads(); }
+  const uint32_t p0 = base + threadIdx.x * 4;
+  uint8_t c[4]; uint32_t fm = 0, cnt = 0;
+  uint8_t prev = (p0 > 0 && p0 - 1 < n) ? u[p0 - 1] : 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t p = p0 + j;
-      c[j] = p < n ? u[p] : 0;
-      if (p < n && (p == 0 || c[j] != prev)) { fm |= 1u << j; cnt++; }
-      prev = c[j];
-    }
+  for (int j = 0; j < 4; j++) {
+    const uint32_t p = p0 + j;
+    c[j] = p < n ? u[p] : 0;
+    if (p < n && (p == 0 || c[j] != prev)) { fm |= 1u << j; cnt++; if (!WRITE) used[c[j]] = 1; }   // every used byte value starts a run
+    prev = c[j];
+  }
+  if (!WRITE) {
+    cnt = block_sum<1024>(cnt, sm);                      // (barrier inside: used[] is complete)
+    if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = cnt;
+    if (threadIdx.x < 256 && used[threadIdx.x]) uflag[(size_t)blk * 258 + threadIdx.x] = 1;
+  } else {
+    uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
+    uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
     uint32_t tot;
-    uint32_t o = carry + block_excl_sum<1024>(cnt, sm, tot);
+    uint32_t o = tcnt[(size_t)blk * tpb + tile] + block_excl_sum<1024>(cnt, sm, tot);
 #pragma unroll
     for (int j = 0; j < 4; j++) if ((fm >> j) & 1u) { hpos[o] = p0 + j; hsym[o] = c[j]; o++; }
-    carry += tot;
   }
-  if (threadIdx.x == 0) mb.nheads[blk] = carry;
+}
+// per block: exclusive scan of the tile counts (tpb <= 1024), number of heads, used-symbol list
+__global__ __launch_bounds__(1024) void mtf_head_scan(MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb, const uint32_t* __restrict__ uflag) {
+  __shared__ uint32_t sm[16];
+  const uint32_t blk = blockIdx.x;
+  uint32_t tot;
+  const uint32_t v = threadIdx.x < tpb ? tcnt[(size_t)blk * tpb + threadIdx.x] : 0u;
+  const uint32_t ex = block_excl_sum<1024>(v, sm, tot);
+  if (threadIdx.x < tpb) tcnt[(size_t)blk * tpb + threadIdx.x] = ex;
+  if (threadIdx.x == 0) mb.nheads[blk] = tot;
+  const uint32_t f = threadIdx.x < 256 ? uflag[(size_t)blk * 258 + threadIdx.x] : 0u;
+  uint32_t asz;
+  const uint32_t ax = block_excl_sum<1024>(f, sm, asz);
+  if (f) mb.alist[(size_t)blk * 256 + ax] = (uint8_t)threadIdx.x;
+  if (threadIdx.x == 0) mb.asz[blk] = asz;
 }
 
 // ---- C1: MTF list at the start of every chunk of 256 heads.
@@ -201,50 +214,65 @@ __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
   }
 }
 
-// ---- D: RLE2 symbols + histogram.  One workgroup per block.
-__global__ __launch_bounds__(1024) void mtf_emit(uint32_t stride, const uint32_t* __restrict__ blen, MtfBufs mb) {
+// ---- D: RLE2 symbols + histogram.  Tiles of 4096 heads: count -> per-block scan -> write (+ tile histogram
+// folded into the block's freq[] with atomics; freq is zeroed by the host, the scan kernel adds the end-of-block symbol).
+template <bool WRITE>
+__global__ __launch_bounds__(1024) void mtf_emit_tiles(const uint32_t* __restrict__ blen, MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb) {
   __shared__ uint32_t freq[258];
   __shared__ uint32_t sm[16];
-  const uint32_t blk = blockIdx.x, n = blen[blk], H = mb.nheads[blk], asz = mb.asz[blk];
+  const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk], H = mb.nheads[blk];
+  const uint32_t base = tile * MT_TILE;
+  if (base >= H) { if (!WRITE && threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = 0; return; }
   const uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
   const uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
+  if (WRITE) { for (int i = threadIdx.x; i < 258; i += 1024) freq[i] = 0; __syncthreads(); }
+  const uint32_t h0 = base + threadIdx.x * 4;
+  uint32_t lit[4], z[4], nd[4], cnt = 0, rk[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t h = h0 + j;
+    lit[j] = z[j] = nd[j] = rk[j] = 0;
+    if (h < H) {
+      const uint32_t r = hrank[h];
+      const uint32_t len = (h + 1 < H ? hpos[h + 1] : n) - hpos[h];
+      lit[j] = r != 0;
+      rk[j] = r;
+      z[j] = len - lit[j];
+      nd[j] = z[j] ? 31u - (uint32_t)__builtin_clz(z[j] + 1u) : 0u;
+      cnt += lit[j] + nd[j];
+    }
+  }
+  if (!WRITE) {
+    cnt = block_sum<1024>(cnt, sm);
+    if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = cnt;
+    return;
+  }
   uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
-  for (int i = threadIdx.x; i < 258; i += 1024) freq[i] = 0;
-  __syncthreads();
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < H; base += 4096) {
-    const uint32_t h0 = base + threadIdx.x * 4;
-    uint32_t lit[4], z[4], nd[4], cnt = 0, rk[4];
+  uint32_t tot;
+  uint32_t o = tcnt[(size_t)blk * tpb + tile] + block_excl_sum<1024>(cnt, sm, tot);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t h = h0 + j;
-      lit[j] = z[j] = nd[j] = rk[j] = 0;
-      if (h < H) {
-        const uint32_t r = hrank[h];
-        const uint32_t len = (h + 1 < H ? hpos[h + 1] : n) - hpos[h];
-        lit[j] = r != 0;
-        rk[j] = r;
-        z[j] = len - lit[j];
-        nd[j] = z[j] ? 31u - (uint32_t)__builtin_clz(z[j] + 1u) : 0u;
-        cnt += lit[j] + nd[j];
-      }
-    }
-    uint32_t tot;
-    uint32_t o = carry + block_excl_sum<1024>(cnt, sm, tot);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (lit[j]) { A[o++] = (uint16_t)(rk[j] + 1); atomicAdd(&freq[rk[j] + 1], 1u); }
-      const uint32_t v = z[j] + 1u;
-      uint32_t nb1 = 0;
-      for (uint32_t i = 0; i < nd[j]; i++) { const uint32_t bit = (v >> i) & 1u; A[o++] = (uint16_t)bit; nb1 += bit; }
-      if (nd[j]) { if (nb1) atomicAdd(&freq[1], nb1); if (nd[j] - nb1) atomicAdd(&freq[0], nd[j] - nb1); }
-    }
-    carry += tot;
+  for (int j = 0; j < 4; j++) {
+    if (lit[j]) { A[o++] = (uint16_t)(rk[j] + 1); atomicAdd(&freq[rk[j] + 1], 1u); }
+    const uint32_t v = z[j] + 1u;
+    uint32_t nb1 = 0;
+    for (uint32_t i = 0; i < nd[j]; i++) { const uint32_t bit = (v >> i) & 1u; A[o++] = (uint16_t)bit; nb1 += bit; }
+    if (nd[j]) { if (nb1) atomicAdd(&freq[1], nb1); if (nd[j] - nb1) atomicAdd(&freq[0], nd[j] - nb1); }
   }
   __syncthreads();
-  if (threadIdx.x == 0) { A[carry] = (uint16_t)(asz + 1); freq[asz + 1] = 1; mb.npos[blk] = carry + 1; }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < 258; i += 1024) mb.freq[(size_t)blk * 258 + i] = i < asz + 2 ? freq[i] : 0u;
+  for (uint32_t i = threadIdx.x; i < 258; i += 1024) if (freq[i]) atomicAdd(&mb.freq[(size_t)blk * 258 + i], freq[i]);
+}
+__global__ __launch_bounds__(1024) void mtf_emit_scan(MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb) {
+  __shared__ uint32_t sm[16];
+  const uint32_t blk = blockIdx.x, asz = mb.asz[blk];
+  uint32_t tot;
+  const uint32_t v = threadIdx.x < tpb ? tcnt[(size_t)blk * tpb + threadIdx.x] : 0u;
+  const uint32_t ex = block_excl_sum<1024>(v, sm, tot);
+  if (threadIdx.x < tpb) tcnt[(size_t)blk * tpb + threadIdx.x] = ex;
+  if (threadIdx.x == 0) {                               // end-of-block symbol (Bzip2:2137-2139)
+    mb.A[(size_t)blk * mb.a_stride + tot] = (uint16_t)(asz + 1);
+    mb.freq[(size_t)blk * 258 + asz + 1] = 1;
+    mb.npos[blk] = tot + 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -274,13 +302,23 @@ int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const ui
   if (nb == 0) return 0;
   if (nb > w.max_blocks) return CJS_E_INVALID_ARG;
   const uint32_t max_chunks = (w.stride + MTF_CHUNK - 1) / MTF_CHUNK;
-  hipLaunchKernelGGL(mtf_heads, dim3(nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b);
+  // tile counters alias segkeys (dead before mtf_seg_last and after mtf_chunk_lists); used flags alias freq
+  const uint32_t tpb = (w.stride + MT_TILE - 1) / MT_TILE;
+  if (tpb > 1024 || (size_t)tpb > (size_t)w.b.seg_stride * 256) return CJS_E_INVALID_ARG;
+  uint32_t* tcnt = reinterpret_cast<uint32_t*>(w.b.segkeys);
+  CJS_HIP_TRY(hipMemsetAsync(w.b.freq, 0, (size_t)nb * 258 * 4, s));
+  hipLaunchKernelGGL(mtf_head_tiles<false>, dim3(tpb, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b, tcnt, tpb, w.b.freq);
+  hipLaunchKernelGGL(mtf_head_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tpb, w.b.freq);
+  hipLaunchKernelGGL(mtf_head_tiles<true>, dim3(tpb, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b, tcnt, tpb, w.b.freq);
   const uint32_t max_segs = (max_chunks + MTF_SEG - 1) / MTF_SEG;
   hipLaunchKernelGGL(mtf_seg_last, dim3(max_segs, nb), dim3(256), 0, s, w.b);
   hipLaunchKernelGGL(mtf_seg_scan, dim3(nb), dim3(256), 0, s, w.b);
   hipLaunchKernelGGL(mtf_chunk_lists, dim3(max_segs, nb), dim3(1024), 0, s, w.b);
   hipLaunchKernelGGL(mtf_replay, dim3((max_chunks + 255) / 256, nb), dim3(256), 0, s, w.stride, w.b);
-  hipLaunchKernelGGL(mtf_emit, dim3(nb), dim3(1024), 0, s, w.stride, d_blen, w.b);
+  CJS_HIP_TRY(hipMemsetAsync(w.b.freq, 0, (size_t)nb * 258 * 4, s));
+  hipLaunchKernelGGL(mtf_emit_tiles<false>, dim3(tpb, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpb);
+  hipLaunchKernelGGL(mtf_emit_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tpb);
+  hipLaunchKernelGGL(mtf_emit_tiles<true>, dim3(tpb, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpb);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
 }
