@@ -6,7 +6,7 @@
 //     So: compact the heads (position, symbol), MTF only over the heads, and derive the RLE2 symbols
 //     of each (head, run length) pair locally: [rank+1] followed by the bijective base-2 digits of
 //     (run length - 1).
-//   * MTF over heads is chunked (256 heads per chunk).  The list at a chunk start is "symbols ordered
+//   * MTF over heads is chunked (512 heads per chunk).  The list at a chunk start is "symbols ordered
 //     by last occurrence before the chunk" = a rank-by-counting over <=256 keys, produced by one
 //     workgroup per block that walks the chunks; the chunks are then replayed independently, one lane
 //     per chunk with its list in LDS (padded rows, no bank aliasing between lanes).
@@ -16,7 +16,7 @@
 
 namespace cjs {
 
-constexpr int MTF_CHUNK = 256;
+constexpr int MTF_CHUNK = 512;
 
 // ---- A: used-symbol list + run-head compaction.  Tiles of 4096 bytes: count -> per-block scan -> write.
 // tcnt[blk * tpb + tile] and the used flags (uflag[blk * 258 + byte], zeroed by the host) alias buffers that
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1024) void mtf_head_scan(MtfBufs mb, uint32_t* __re
   if (threadIdx.x == 0) mb.asz[blk] = asz;
 }
 
-// ---- C1: MTF list at the start of every chunk of 256 heads.
+// ---- C1: MTF list at the start of every chunk of 512 heads.
 // The list before a chunk = used symbols ordered by (last occurrence before the chunk, descending), never-seen
 // symbols after them in ascending byte order.  Three kernels so that the serial chain is 32 chunks long, not ~1000:
 //   mtf_seg_last  : per segment of 32 chunks, last head index of every byte value inside the segment
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
       lists[(size_t)c * 256 + p] = (uint8_t)d;
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
+    if (threadIdx.x < MTF_CHUNK) {
       const uint32_t h = c * MTF_CHUNK + threadIdx.x;
       if (h < H) atomicMax(&keys[hsym[h]], (int)(256 + h));
     }
