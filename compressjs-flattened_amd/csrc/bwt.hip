@@ -35,37 +35,101 @@ __host__ __device__ __forceinline__ uint32_t xcd_grid(uint32_t T) { return ((T +
 // ------------------------------------------------------------------------------------------
 // LSD radix sort pass: histogram -> per-bin scan over tiles -> stable scatter
 // ------------------------------------------------------------------------------------------
-template <typename K>
-__global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, uint32_t n, int shift,
+// Segments: the array is nseg runs of `stride` elements (the last one n_last) that are sorted independently in the
+// same launches (round 1 of the suffix sort: one segment per block, so the block id needs no digit passes of its
+// own).  Tiles never straddle segments: segment s owns tiles [s*tps, (s+1)*tps).  A plain sort is one segment.
+struct SegGeom { uint32_t nseg, stride, n_last, tps; };
+struct TileRef { uint32_t seg, off, nvalid; uint64_t base; };
+__device__ __forceinline__ TileRef tile_ref(const SegGeom& sg, uint32_t tile) {
+  TileRef t;
+  t.seg = tile / sg.tps;
+  t.off = (tile - t.seg * sg.tps) * RS_TILE;
+  const uint32_t sn = t.seg + 1 == sg.nseg ? sg.n_last : sg.stride;
+  t.nvalid = t.off < sn ? (sn - t.off < RS_TILE ? sn - t.off : RS_TILE) : 0u;
+  t.base = (uint64_t)t.seg * sg.stride + t.off;
+  return t;
+}
+// Key source of the first pass of round 1: keys are made on the fly from the block bytes (no key array is ever
+// written for them).  key = leading nsym symbols | block parity above them (adjacent blocks must not compare equal);
+// cyclic: bytes, wrapping; sentinel: 9-bit symbols byte+1, 0 = past the end.  value = position in the block.
+struct GenSrc { const uint8_t* T; int cyclic, nsym; };
+constexpr uint32_t GEN_PAD = 8;
+// stages the tile's bytes (+GEN_PAD lookahead) in LDS; returns the byte offset of the tile's first byte inside tb (< 4):
+// tiles that do not touch the end of their block are copied as aligned 32-bit words from the aligned-down address
+__device__ __forceinline__ uint32_t gen_stage(const GenSrc& gs, const SegGeom& sg, const TileRef& t, uint8_t* tb) {
+  const uint32_t sn = t.seg + 1 == sg.nseg ? sg.n_last : sg.stride;
+  const uint8_t* src = gs.T + (size_t)t.seg * sg.stride;
+  if (t.off + RS_TILE + GEN_PAD <= sn) {
+    const uintptr_t a = (uintptr_t)(src + t.off);
+    const uint32_t* al = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    uint32_t* tw = reinterpret_cast<uint32_t*>(tb);
+    for (uint32_t i = threadIdx.x; i < (RS_TILE + GEN_PAD) / 4 + 1; i += 256) tw[i] = al[i];
+    return (uint32_t)(a & 3);
+  }
+  for (uint32_t i = threadIdx.x; i < RS_TILE + GEN_PAD; i += 256) {
+    uint32_t p = t.off + i;
+    if (p >= sn) p = gs.cyclic ? p % sn : sn - 1;      // sentinel: never used (masked by position)
+    tb[i] = t.nvalid ? src[p] : 0;
+  }
+  return 0;
+}
+__device__ __forceinline__ uint64_t gen_key(const GenSrc& gs, const SegGeom& sg, const TileRef& t, const uint8_t* tb, uint32_t tb0, uint32_t loc) {
+  // the 8 bytes at tb[tb0 + loc ..] from three aligned LDS words
+  const uint32_t* tw = reinterpret_cast<const uint32_t*>(tb) + ((tb0 + loc) >> 2);
+  const uint32_t a0 = tw[0], a1 = tw[1], a2 = tw[2], sh = (tb0 + loc) & 3u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sh), hi = __builtin_amdgcn_alignbyte(a2, a1, sh);   // byte j of (hi:lo) = tb[loc + j]
+  uint64_t k = 0;
+  if (gs.cyclic) {
+    k = ((uint64_t)__builtin_bswap32(lo) << 24) | (uint64_t)(__builtin_bswap32(hi) >> 8);     // 7 bytes, first byte on top
+    k >>= 8 * (7 - gs.nsym);
+    k |= (uint64_t)(t.seg & 1u) << (8 * gs.nsym);
+  } else {
+    const uint32_t sn = t.seg + 1 == sg.nseg ? sg.n_last : sg.stride;
+    const uint64_t both = ((uint64_t)hi << 32) | lo;
+    for (int j = 0; j < gs.nsym; j++) k = (k << 9) | (t.off + loc + j < sn ? (uint32_t)((both >> (8 * j)) & 0xFFu) + 1u : 0u);
+    k |= (uint64_t)(t.seg & 1u) << (9 * gs.nsym);
+  }
+  return k;
+}
+
+template <typename K, bool GEN>
+__global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGeom sg, GenSrc gs, int shift,
                                                uint32_t* __restrict__ hist, uint32_t T) {
   __shared__ uint32_t h[4][256];
+  __shared__ __attribute__((aligned(16))) uint8_t tb[GEN ? RS_TILE + GEN_PAD + 16 : 16];
   const int tid = threadIdx.x, w = tid >> 6;
   for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
-  __syncthreads();
   const uint32_t tile = blockIdx.x;
-  const uint64_t base = (uint64_t)tile * RS_TILE;
+  const TileRef t = tile_ref(sg, tile);
+  uint32_t tb0 = 0;
+  if (GEN) tb0 = gen_stage(gs, sg, t, tb);
+  __syncthreads();
 #pragma unroll 4
   for (int it = 0; it < 16; it++) {
-    uint64_t idx = base + (uint32_t)it * 256 + tid;
-    if (idx < n) atomicAdd(&h[w][(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+    const uint32_t loc = (uint32_t)it * 256 + tid;
+    if (loc < t.nvalid) {
+      const uint64_t k = GEN ? gen_key(gs, sg, t, tb, tb0, loc) : (uint64_t)keys[t.base + loc];
+      atomicAdd(&h[w][(uint32_t)(k >> shift) & 255u], 1u);
+    }
   }
   __syncthreads();
   hist[(size_t)tid * T + tile] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
 }
 
-// one workgroup per digit value: exclusive scan of that digit's per-tile counts
-__global__ __launch_bounds__(1024) void rs_scan_bins(uint32_t* __restrict__ hist, uint32_t T, uint32_t* __restrict__ bintot) {
+// one workgroup per (digit value, segment): exclusive scan of that digit's per-tile counts inside the segment
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rs_scan_bins(uint32_t* __restrict__ hist, uint32_t T, uint32_t tps, uint32_t* __restrict__ bintot) {
   __shared__ uint32_t sm[16];
-  uint32_t* p = hist + (size_t)blockIdx.x * T;
+  uint32_t* p = hist + (size_t)blockIdx.x * T + (size_t)blockIdx.y * tps;
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < T; base += 1024) {
+  for (uint32_t base = 0; base < tps; base += BLOCK) {
     uint32_t i = base + threadIdx.x;
-    uint32_t v = i < T ? p[i] : 0u, total;
-    uint32_t ex = block_excl_sum<1024>(v, sm, total);
-    if (i < T) p[i] = carry + ex;
+    uint32_t v = i < tps ? p[i] : 0u, total;
+    uint32_t ex = block_excl_sum<BLOCK>(v, sm, total);
+    if (i < tps) p[i] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0) bintot[blockIdx.x] = carry;
+  if (threadIdx.x == 0) bintot[(size_t)blockIdx.y * 256 + blockIdx.x] = carry;
 }
 
 __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
@@ -79,29 +143,43 @@ __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
   return peers;
 }
 
-template <typename K>
+template <typename K, bool GEN>
 __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                  K* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
+                                                  K* __restrict__ kout, uint32_t* __restrict__ vout, SegGeom sg, GenSrc gs, int shift,
                                                   const uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ bintot) {
-  __shared__ K skey[RS_TILE];
+  __shared__ K skey[RS_TILE + 2];
   __shared__ uint32_t sval[RS_TILE];
   __shared__ uint32_t wcnt[4][256];
   __shared__ uint32_t goff[256];
   __shared__ uint32_t sm[4];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint32_t tile = blockIdx.x;
-  const uint64_t base = (uint64_t)tile * RS_TILE;
-  const uint32_t nvalid = (uint32_t)((uint64_t)n - base < RS_TILE ? (uint64_t)n - base : RS_TILE);
+  const TileRef t = tile_ref(sg, tile);
+  const uint64_t base = t.base;
+  const uint32_t nvalid = t.nvalid;
   for (int i = tid; i < 1024; i += 256) (&wcnt[0][0])[i] = 0;
   K k[16];
   uint32_t v[16];
   uint32_t rk[16];
+  if (GEN) {
+    uint8_t* tb = reinterpret_cast<uint8_t*>(skey);     // skey is not written before the ranking is done
+    const uint32_t tb0 = gen_stage(gs, sg, t, tb);
+    __syncthreads();
 #pragma unroll
-  for (int s = 0; s < 16; s++) {
-    const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
-    const bool ok = loc < nvalid;
-    k[s] = ok ? kin[base + loc] : (K)~(K)0;
-    v[s] = ok ? vin[base + loc] : 0u;
+    for (int s = 0; s < 16; s++) {
+      const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+      const bool ok = loc < nvalid;
+      k[s] = ok ? (K)gen_key(gs, sg, t, tb, tb0, loc) : (K)~(K)0;
+      v[s] = ok ? t.off + loc : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+      const bool ok = loc < nvalid;
+      k[s] = ok ? kin[base + loc] : (K)~(K)0;
+      v[s] = ok ? vin[base + loc] : 0u;
+    }
   }
   __syncthreads();
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -122,9 +200,9 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
     uint32_t total;
     const uint32_t ex = block_excl_sum<256>(c0 + c1 + c2 + c3, sm, total);
     uint32_t tot2;
-    const uint32_t binbase = block_excl_sum<256>(bintot[tid], sm, tot2);
+    const uint32_t binbase = block_excl_sum<256>(bintot[(size_t)t.seg * 256 + tid], sm, tot2);
     wcnt[0][tid] = ex; wcnt[1][tid] = ex + c0; wcnt[2][tid] = ex + c0 + c1; wcnt[3][tid] = ex + c0 + c1 + c2;
-    goff[tid] = binbase + hist[(size_t)tid * T + tile] - ex;
+    goff[tid] = t.seg * sg.stride + binbase + hist[(size_t)tid * T + tile] - ex;
   }
   __syncthreads();
 #pragma unroll
@@ -707,23 +785,24 @@ __global__ __launch_bounds__(256) void bwt_emit(const uint8_t* __restrict__ T, G
 // ------------------------------------------------------------------------------------------
 static int bits_for(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 size_t BwtWork::bytes_needed(size_t cap) {
-  const size_t T = (cap + RS_TILE - 1) / RS_TILE + 1;
+  const size_t T = hist_tiles_for(cap);
   size_t b = 0;
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
   add(cap * 8); add(cap * 8); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4);  // key x2, val x2, pos x2, gord
   add(cap * 4); add(cap * 4);           // R, SA
-  add(256 * T * 4); add(256 * 4); add(3 * T * 4); add(64); add(16 * 256 * 4);
+  add(256 * T * 4); add(256 * segs_for(cap) * 4); add(3 * T * 4); add(64); add(16 * 256 * 4);
   return b + 4096;
 }
 int BwtWork::carve(Arena& a, size_t cap_) {
   cap = cap_;
-  const size_t T = (cap + RS_TILE - 1) / RS_TILE + 1;
+  const size_t T = hist_tiles_for(cap);
+  hist_tiles = (uint32_t)T; bintot_segs = (uint32_t)segs_for(cap);
   key[0] = a.take<uint64_t>(cap); key[1] = a.take<uint64_t>(cap);
   val[0] = a.take<uint32_t>(cap); val[1] = a.take<uint32_t>(cap);
   pos[0] = a.take<uint32_t>(cap); pos[1] = a.take<uint32_t>(cap);
   gord = a.take<uint32_t>(cap);
   R = a.take<uint32_t>(cap); SA = a.take<uint32_t>(cap);
-  hist = a.take<uint32_t>(256 * T); bintot = a.take<uint32_t>(256);
+  hist = a.take<uint32_t>(256 * T); bintot = a.take<uint32_t>(256 * (size_t)bintot_segs);
   tile_cnt = a.take<uint32_t>(3 * T); counters = a.take<uint32_t>(16);
   ghist = a.take<uint32_t>(16 * 256);
   if (!counters || !ghist) return CJS_E_OUT_OF_MEMORY;
@@ -755,15 +834,18 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
 
 template <typename K>
 static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
-                        LaunchTimes* lt) {
-  const uint32_t T = (n + RS_TILE - 1) / RS_TILE;
+                        LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr) {
+  const uint32_t T1 = (n + RS_TILE - 1) / RS_TILE;
+  const SegGeom sg = seg ? *seg : SegGeom{1u, n, n, T1};
+  const uint32_t T = sg.nseg * sg.tps;
+  if (T > w.hist_tiles || sg.nseg > w.bintot_segs) return CJS_E_INVALID_ARG;
   K* kk[2] = {k0, k1}; uint32_t* vv[2] = {v0, v1};
   const int npasses = (hi_bit - lo_bit + 7) / 8;
   // Measured on MI355X (100 MB, level 9): the look-back passes are correct but slower than the three-kernel
   // passes (BWT 26.4 ms vs 23.2 ms: one lane per digit walks predecessor tiles serially, ~1 us per sc1 poll),
   // so they stay opt-in until the look-back is widened to a wave per window.
   static const bool classic = getenv("CJS_ONESWEEP") == nullptr;
-  if (!classic && w.ghist && npasses >= 1 && npasses <= 8 && n < (1u << 30)) {
+  if (!classic && !seg && !gen && w.ghist && npasses >= 1 && npasses <= 8 && n < (1u << 30)) {
     // one histogram read for all digits + look-back scatter passes
     uint32_t* gbase = w.ghist + 8 * 256;
     uint32_t* ticket = w.counters + 8; uint32_t* errflag = w.counters + 9;
@@ -782,11 +864,16 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
     CJS_HIP_TRY(hipGetLastError());
     return 0;
   }
+  const GenSrc g0{nullptr, 0, 0};
   for (int shift = lo_bit; shift < hi_bit; shift += 8) {
-    hipLaunchKernelGGL(rs_hist<K>, dim3(T), dim3(256), 0, s, kk[cur], n, shift, w.hist, T);
-    hipLaunchKernelGGL(rs_scan_bins, dim3(256), dim3(1024), 0, s, w.hist, T, w.bintot);
+    const bool first_gen = gen && shift == lo_bit;        // the first pass makes its keys from the block bytes
+    if (first_gen) hipLaunchKernelGGL((rs_hist<K, true>), dim3(T), dim3(256), 0, s, kk[cur], sg, *gen, shift, w.hist, T);
+    else hipLaunchKernelGGL((rs_hist<K, false>), dim3(T), dim3(256), 0, s, kk[cur], sg, g0, shift, w.hist, T);
+    if (sg.tps <= 512) hipLaunchKernelGGL(rs_scan_bins<256>, dim3(256, sg.nseg), dim3(256), 0, s, w.hist, T, sg.tps, w.bintot);
+    else hipLaunchKernelGGL(rs_scan_bins<1024>, dim3(256, sg.nseg), dim3(1024), 0, s, w.hist, T, sg.tps, w.bintot);
     if (lt) lt->begin(s, n);
-    hipLaunchKernelGGL(rs_scatter<K>, dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], n, shift, w.hist, T, w.bintot);
+    if (first_gen) hipLaunchKernelGGL((rs_scatter<K, true>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, *gen, shift, w.hist, T, w.bintot);
+    else hipLaunchKernelGGL((rs_scatter<K, false>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, g0, shift, w.hist, T, w.bintot);
     if (lt) lt->end(s);
     cur = 1 - cur;
   }
@@ -854,17 +941,26 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
 
   int c = 0, pc = 0;        // current key/val buffer, current pos buffer
   CJS_HIP_TRY(hipMemsetAsync(w.counters, 0, 64, s));
-  // round 0 sorts by as many leading symbols as fit beside the block id in 64 bits
-  const int blk_bits = bits_for(nb - 1), sym_bits = cyclic ? 8 : 9;
-  int nsym = (64 - blk_bits) / sym_bits;
+  // round 1 sorts by the leading symbols.  Segmented (normal case): one segment per block, keys generated from the
+  // block bytes in the first pass, 7 symbols + the block parity.  Fallback (more tiles/segments than the workspace
+  // was carved for, e.g. many tiny blocks): keys materialised with the block id on top, sorted as one array.
+  const int sym_bits = cyclic ? 8 : 9;
+  const uint32_t tps = ((nb > 1 ? stride : n_last) + RS_TILE - 1) / RS_TILE;
+  const bool segmented = (uint64_t)nb * tps <= w.hist_tiles && nb <= w.bintot_segs && getenv("CJS_NO_SEGMENTED_SORT") == nullptr;
+  const int blk_bits = bits_for(nb - 1);
+  int nsym = segmented ? 7 : (64 - blk_bits) / sym_bits;
   if (nsym > 7) nsym = 7;
-  hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0]);
+  const SegGeom sg{nb, stride, n_last, tps};
+  const GenSrc gen{d_T, cyclic ? 1 : 0, nsym};
+  if (!segmented) hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0]);
   uint32_t A = M, h = (uint32_t)nsym, rounds = 0;
   w.no_large_groups = false;
-  int bits = nsym * sym_bits + blk_bits;
+  int bits = nsym * sym_bits + (segmented ? 0 : blk_bits);
   for (;;) {
-    if (rounds == 0) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
-    else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt));
+    if (rounds == 0) {
+      if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
+      else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
+    } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters);

@@ -64,7 +64,11 @@ struct BwtWork {
   uint32_t* counters = nullptr;  // 16: [0] survivors [1] groups [8] tile ticket [9] look-back error
   uint32_t* ghist = nullptr;     // [8][256] digit histograms + [8][256] their exclusive scans (onesweep passes)
   uint32_t* h_counters = nullptr;  // pinned host mirror
+  uint32_t hist_tiles = 0, bintot_segs = 0;   // capacity of hist (tiles) and bintot (segments)
   bool no_large_groups = false;    // per bwt_run: no unresolved group exceeds the tile sorter's limit any more
+  // segmented sorts round every block up to whole tiles: room for one extra tile per 64 Ki elements
+  static size_t hist_tiles_for(size_t cap) { return (cap + RS_TILE - 1) / RS_TILE + cap / 65536 + 258; }
+  static size_t segs_for(size_t cap) { return cap / 65536 + 2; }
   static size_t bytes_needed(size_t cap);
   int carve(Arena& a, size_t cap);
 };

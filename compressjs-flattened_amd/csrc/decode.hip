@@ -523,6 +523,7 @@ int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32
   if (!rc) rc = dmalloc((void**)&d_srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_err, 4 * (size_t)nb);
   const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
   if (!rc) rc = dmalloc((void**)&sw.hist, 256 * T * 4); if (!rc) rc = dmalloc((void**)&sw.bintot, 256 * 4);
+  sw.hist_tiles = (uint32_t)T; sw.bintot_segs = 1;
   if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
   if (rc) { cleanup(); return rc; }
   hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_T, stride, d_blocks, d_key0, d_val0);
@@ -667,6 +668,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   if (!rc) rc = dmalloc((void**)&d_srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_err, 4 * (size_t)nb);
   const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
   if (!rc) rc = dmalloc((void**)&sw.hist, 256 * T * 4); if (!rc) rc = dmalloc((void**)&sw.bintot, 256 * 4);
+  sw.hist_tiles = (uint32_t)T; sw.bintot_segs = 1;
   if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipMemsetAsync(d_err, 0, 4 * (size_t)nb, s) != hipSuccess) rc = CJS_E_HIP;
   if (rc) { cleanup(); return rc; }
