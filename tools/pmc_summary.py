@@ -34,7 +34,9 @@ for k in sorted(set(f) | set(w)):
     if k.startswith(("rs_", "bwt_", "rle_", "mtf_", "huff_", "pack_")):
         tot += fb + wb
 out["pipeline_hbm_bytes_per_step"] = round(tot)
-k = "rs_scatter<unsigned long>"
-if k in out["kernels"]:
-    out["rs_scatter_hbm_bytes_per_launch"] = out["kernels"][k]["hbm_bytes_per_launch"]
+sc = [v for k, v in out["kernels"].items() if k.startswith("rs_scatter<unsigned long")]     # all template variants of the 64-bit scatter
+if sc:
+    calls = sum(v["launches_per_step"] for v in sc)
+    out["rs_scatter_hbm_bytes_per_launch"] = round(sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in sc) / calls)
+    out["rs_scatter_launches_per_step"] = calls
 print(json.dumps(out, indent=1))
