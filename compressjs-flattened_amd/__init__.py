@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libcjs_hip.so")
+LIB_PATH = os.environ.get("CJS_HIP_LIB") or os.path.join(PKG_DIR, "libcjs_hip.so")   # same override as the N-API addon
 u8p = ctypes.POINTER(ctypes.c_uint8)
 
 

@@ -381,12 +381,12 @@ __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint3
   for (int it = 0; it < 16; it++) {
     const uint64_t a = base + (uint32_t)it * 256 + threadIdx.x;
     if (a < A) {
-      const uint32_t blk = pos[a] / g.stride, n = blk_len(g, blk);
-      uint64_t j = (uint64_t)val[a] + h;
+      const uint32_t blk = __builtin_nontemporal_load(pos + a) / g.stride, n = blk_len(g, blk);
+      uint64_t j = (uint64_t)__builtin_nontemporal_load(val + a) + h;
       uint32_t kk;
       if (cyclic) { if (j >= n) j %= n; kk = R[(size_t)blk * g.stride + j] + 1u; }
       else kk = j < n ? R[(size_t)blk * g.stride + j] + 1u : 0u;
-      key[a] = ((uint64_t)gord[a] << 20) | kk;
+      __builtin_nontemporal_store(((uint64_t)__builtin_nontemporal_load(gord + a) << 20) | kk, key + a);
     }
   }
 }
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
 #pragma unroll 4
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
-    sk[e + 1] = e < nvalid ? key[base + e] : ~0ull;
+    sk[e + 1] = e < nvalid ? __builtin_nontemporal_load(key + base + e) : ~0ull;     // streamed once: keep the L2 for R
   }
   if (tid == 0) {
     sk[0] = base ? key[base - 1] : ~0ull;
@@ -523,15 +523,15 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
         head_a = carry - 1u;
         if (!FIRST) keeps_rank = head_a == 0 || (key[head_a] >> 20) != (key[head_a - 1] >> 20);
       }
-      const uint32_t p = FIRST ? (uint32_t)a : pos[a], vv = val[a];
+      const uint32_t p = FIRST ? (uint32_t)a : __builtin_nontemporal_load(pos + a), vv = __builtin_nontemporal_load(val + a);
       const uint32_t blk = p / g.stride;
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
       if (!keeps_rank) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
-      if ((ms >> lane) & 1ull) SA[p] = vv;
+      if ((ms >> lane) & 1ull) __builtin_nontemporal_store(vv, SA + p);
       else {
         const uint32_t so = sbase + wp_s[wi] + (uint32_t)__popcll(~ms & lt);
         const uint32_t ho = hbase + wp_h[wi] + (uint32_t)__popcll(mh & ~ms & le);
-        nval[so] = vv; npos[so] = p; ngord[so] = ho - 1u;
+        __builtin_nontemporal_store(vv, nval + so); __builtin_nontemporal_store(p, npos + so); __builtin_nontemporal_store(ho - 1u, ngord + so);
       }
     }
   }
@@ -764,13 +764,20 @@ __global__ __launch_bounds__(256) void bwt_pidx(Geom g, int cyclic, int leftover
   if (threadIdx.x == 0) pidx[blk] = r0 + cnt - 1u;
 }
 
+// Tiles of 4096 positions, dealt to the XCDs in contiguous ranges: a block's text (the random-access side) is then
+// fetched into one L2 instead of all eight; the suffix array streams through non-temporally.
 __global__ __launch_bounds__(256) void bwt_emit(const uint8_t* __restrict__ T, Geom g, int cyclic, uint32_t M,
-                                                const uint32_t* __restrict__ SA, const uint32_t* __restrict__ R, uint8_t* __restrict__ U) {
-  for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < M; a += (uint64_t)gridDim.x * 256) {
+                                                const uint32_t* __restrict__ SA, const uint32_t* __restrict__ R, uint8_t* __restrict__ U, uint32_t Tn) {
+  const uint32_t tile = xcd_tile(blockIdx.x, Tn);
+  if (tile >= Tn) return;
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint64_t a = (uint64_t)tile * RS_TILE + (uint32_t)it * 256 + threadIdx.x;
+    if (a >= M) break;
     const uint32_t blk = (uint32_t)(a / g.stride), p = (uint32_t)(a - (uint64_t)blk * g.stride), n = blk_len(g, blk);
     const uint8_t* t = T + (size_t)blk * g.stride;
     uint8_t* u = U + (size_t)blk * g.stride;
-    const uint32_t s = SA[a];
+    const uint32_t s = __builtin_nontemporal_load(SA + a);
     if (cyclic) u[p] = t[s ? s - 1 : n - 1];
     else {
       const uint32_t p0 = R[(size_t)blk * g.stride];
@@ -990,7 +997,10 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     bits = 20 + bits_for(NG ? NG - 1 : 0);
   }
   hipLaunchKernelGGL(bwt_pidx, dim3(nb), dim3(256), 0, s, g, (int)cyclic, (int)(A != 0), w.R, d_pidx);
-  hipLaunchKernelGGL(bwt_emit, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, M, w.SA, w.R, d_U);
+  {
+    const uint32_t Tn = (M + RS_TILE - 1) / RS_TILE;
+    hipLaunchKernelGGL(bwt_emit, dim3(xcd_grid(Tn)), dim3(256), 0, s, d_T, g, (int)cyclic, M, w.SA, w.R, d_U, Tn);
+  }
   CJS_HIP_TRY(hipGetLastError());
   if (stats) {
     CJS_HIP_TRY(hipStreamSynchronize(s));

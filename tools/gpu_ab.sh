@@ -3,5 +3,5 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 for e in "$@"; do
   echo "== $e"
-  env $e timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify 2>&1 | grep -o '"ms_per_step": [0-9.]*\|"stage_ms_per_step": {[^}]*}' || exit 1
+  env $(echo $e | sed "s#=ab/#=$GRAFT_REPO_ROOT/ab/#") timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify 2>&1 | grep -o '"ms_per_step": [0-9.]*\|"stage_ms_per_step": {[^}]*}' || exit 1
 done
