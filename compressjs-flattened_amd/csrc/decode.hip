@@ -104,6 +104,35 @@ struct DecShared {
   uint32_t byte_count[256];
 };
 
+// big-endian 32-bit word `dw` of the stream, zeros past the end (the reference's reader yields zero bits there, :149)
+__device__ __forceinline__ uint32_t load_be32(const uint8_t* in, uint64_t n, uint64_t dw) {
+  const uint64_t b = dw * 4;
+  if (b + 4 <= n) return __builtin_bswap32(*reinterpret_cast<const uint32_t*>(in + b));       // `in` is a hipMalloc'd copy: 4-byte aligned
+  uint32_t v = 0;
+  for (int i = 0; i < 4; i++) v = (v << 8) | (b + i < n ? in[b + i] : 0u);
+  return v;
+}
+// 4096-bit register window on the stream: lane j holds words base+j (A) and base+64+j (B); all cursor state is wave-uniform
+struct BitWin {
+  const uint8_t* in; uint64_t n; uint64_t base; uint32_t A, B;
+  __device__ __forceinline__ void init(uint64_t pos, int lane) { base = pos >> 5; A = load_be32(in, n, base + lane); B = load_be32(in, n, base + 64 + lane); }
+  __device__ __forceinline__ void ensure(uint64_t pos, int lane) {        // afterwards (pos >> 5) - base < 64
+    while ((pos >> 5) - base >= 64) {
+      if ((pos >> 5) - base >= 128) { init(pos, lane); return; }
+      A = B; base += 64; B = load_be32(in, n, base + 64 + lane);
+    }
+  }
+  __device__ __forceinline__ uint32_t word(uint32_t k) const { return k < 64 ? __builtin_amdgcn_readlane(A, k) : __builtin_amdgcn_readlane(B, k - 64); }
+  __device__ __forceinline__ uint32_t peek(uint64_t pos, int k) const {   // k <= 32 bits at pos (uniform), window must cover it
+    const uint32_t d = (uint32_t)((pos >> 5) - base);
+    const uint64_t w = ((uint64_t)word(d) << 32) | word(d + 1);
+    return (uint32_t)((w << (pos & 31)) >> (64 - k));
+  }
+};
+
+__device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
+#define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
+template <int V>
 __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand,
                                                       uint32_t dbuf_size, uint8_t* __restrict__ tt_all, uint32_t* __restrict__ hist_all,
                                                       BlockOut* __restrict__ outs) {
@@ -117,6 +146,7 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
   BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
   int err = 0;
   uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0;
+  DEC_MARK(0);
   if (lane == 0) {                                           // header (:1440-1493)
     bo.crc = r.get(16) << 16; bo.crc |= r.get(16);
     if (r.get(1)) err = CJS_E_OBSOLETE_INPUT;
@@ -160,8 +190,12 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
       }
     }
   }
-  err = __shfl(err, 0, 64);
-  sym_total = __shfl(sym_total, 0, 64); group_count = __shfl(group_count, 0, 64); n_sel = __shfl(n_sel, 0, 64);
+  DEC_MARK(1);
+  // lane 0's results become wave-uniform scalars (readfirstlane, not a shuffle: the compiler must KNOW they are uniform,
+  // or the whole symbol loop is compiled as divergent code under exec masks)
+  err = __builtin_amdgcn_readfirstlane(err);
+  sym_total = __builtin_amdgcn_readfirstlane(sym_total); group_count = __builtin_amdgcn_readfirstlane(group_count);
+  n_sel = __builtin_amdgcn_readfirstlane(n_sel);
   const uint32_t sym_count = sym_total + 2;
   __builtin_amdgcn_wave_barrier();
   if (!err) {
@@ -208,12 +242,105 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
     for (int i = lane; i < 256; i += 64) { S.byte_count[i] = 0; S.mtf[i] = (uint8_t)i; }
   }
   __builtin_amdgcn_wave_barrier();
+  DEC_MARK(2);
+  uint32_t dbuf_count = 0;
+  r.pos = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
+  r.wbyte = ~0ull >> 4;
+  orig = __builtin_amdgcn_readfirstlane(orig);
+  if (V == 2) {
+    // symbol loop (:1597-1670), wave-cooperative.  All control state is wave-uniform.
+    //  * Huffman: every lane looks up the code that WOULD start at bit pos+lane (bits from a register window, one LDS
+    //    read of the 10-bit table); the real code chain is then followed with readlane hops (length -> next lane),
+    //    so one LDS round trip serves every code inside the next 64 bits;
+    //  * MTF list as bytes in one register per lane (position 4*lane+b): pick by readlane, shift by wave_shr DPP;
+    //  * output bytes collect in a register and leave as 64-byte coalesced stores; runs are filled by all lanes.
+    if (!err) {
+      BitWin bw{in, n, 0, 0, 0};
+      uint64_t pos = r.pos;
+      bw.init(pos, lane);
+      uint32_t L = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) L |= (uint32_t)S.sym_to_byte[4 * lane + b] << (8 * b);
+      uint32_t outb = 0, obase = 0;
+      int32_t run_pos = 0; long long run_t = 0;
+      uint32_t selector = 0; int sym_left = 0, g = 0;
+      bool done = false;
+      while (!done && !err) {
+        if (sym_left == 0) {
+          sym_left = 50;
+          if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
+          g = __builtin_amdgcn_readfirstlane((int)S.selectors[selector++]);      // LDS loads count as divergent: say it is uniform
+          if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
+        }
+        bw.ensure(pos, lane);
+        uint32_t e;
+        {
+          const uint32_t d = (uint32_t)((pos >> 5) - bw.base);
+          const uint32_t w0 = bw.word(d), w1 = bw.word(d + 1), w2 = bw.word(d + 2), w3 = bw.word(d + 3);
+          const uint32_t o = (uint32_t)(pos & 31) + (uint32_t)lane, wi = o >> 5;
+          const uint32_t hi = wi == 0 ? w0 : wi == 1 ? w1 : w2, lo = wi == 0 ? w1 : wi == 1 ? w2 : w3;
+          const uint32_t x = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31)) >> 54);
+          e = S.fast[g][x];
+        }
+        uint32_t idx = 0;
+        while (idx < 64 && sym_left > 0) {
+          const uint32_t ee = __builtin_amdgcn_readlane(e, idx);
+          uint32_t next_sym, len;
+          if (ee == 0x1F) { err = CJS_E_DATA_ERROR; break; }
+          if (ee) { next_sym = ee >> 5; len = ee & 31u; }
+          else {                                               // long code: the reference's bit-by-bit rule
+            const uint64_t p0 = pos + idx;
+            int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);
+            const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
+            long long j = bw.peek(p0, i);
+            for (;; i++) {
+              if (i > mx) { err = CJS_E_DATA_ERROR; break; }
+              if (j <= (long long)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
+              j = (j << 1) | bw.peek(p0 + i, 1);
+            }
+            if (err) break;
+            j -= (long long)__builtin_amdgcn_readfirstlane(S.base[g][i]);
+            if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
+            next_sym = __builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]); len = (uint32_t)i;
+          }
+          idx += len; sym_left--;
+          if (next_sym <= 1) {                                 // RUNA / RUNB
+            if (!run_pos) { run_pos = 1; run_t = 0; }
+            run_t += next_sym == 0 ? (long long)run_pos : 2 * (long long)run_pos;
+            run_pos = (int32_t)((uint32_t)run_pos << 1);
+            continue;
+          }
+          if (run_pos) {
+            run_pos = 0;
+            if ((long long)dbuf_count + run_t > (long long)dbuf_size) { err = CJS_E_DATA_ERROR; break; }
+            const uint8_t uc = (uint8_t)(__builtin_amdgcn_readlane(L, 0) & 0xFFu);
+            if ((uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;       // pending singles first
+            for (long long q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
+            dbuf_count += (uint32_t)run_t;
+            obase = dbuf_count;
+          }
+          if (next_sym > sym_total) { done = true; break; }     // EOB
+          if (dbuf_count >= dbuf_size) { err = CJS_E_DATA_ERROR; break; }
+          const uint32_t k = next_sym - 1, q = k >> 2, rb = k & 3u;
+          const uint32_t v = (__builtin_amdgcn_readlane(L, q) >> (8u * rb)) & 0xFFu;
+          const uint32_t up = __builtin_amdgcn_update_dpp(0u, L, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+          const uint32_t shifted = (L << 8) | (lane == 0 ? v : up >> 24);
+          const uint32_t m = (uint32_t)lane < q ? 0xFFFFFFFFu : (uint32_t)lane == q ? (rb == 3 ? 0xFFFFFFFFu : ((1u << (8u * (rb + 1u))) - 1u)) : 0u;
+          L = (shifted & m) | (L & ~m);
+          const uint32_t slot = dbuf_count - obase;
+          outb = (uint32_t)lane == slot ? v : outb;
+          dbuf_count++;
+          if (slot == 63) { tt[obase + lane] = (uint8_t)outb; obase = dbuf_count; }
+        }
+        pos += idx;
+      }
+      if (!err && (uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;
+      if (!err && orig >= dbuf_count) err = CJS_E_DATA_ERROR;    // :1677
+      r.pos = pos > r.nbits ? r.nbits : pos;
+    }
+  } else {
   // symbol loop (:1597-1670).  Executed by ALL lanes on identical (wave-uniform) state, so the serial Huffman
   // decode costs the same as on one lane while the move-to-front shift and the run fills use the 64 lanes.
-  uint32_t dbuf_count = 0;
-  r.pos = __shfl((unsigned long long)r.pos, 0, 64);
-  r.wbyte = ~0ull >> 4;
-  orig = __shfl(orig, 0, 64);
   if (!err) {
     int32_t run_pos = 0; long long run_t = 0;
     uint32_t selector = 0; int sym_left = 0, g = 0;
@@ -281,9 +408,11 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
     }
     if (!err && orig >= dbuf_count) err = CJS_E_DATA_ERROR;    // :1677
   }
+  }
+  DEC_MARK(3);
   __builtin_amdgcn_wave_barrier();
   err = __shfl(err, 0, 64);
-  if (!err) for (int i = lane; i < 256; i += 64) hist_all[(size_t)c * 256 + i] = S.byte_count[i];
+  if (V != 2 && !err) for (int i = lane; i < 256; i += 64) hist_all[(size_t)c * 256 + i] = S.byte_count[i];
   if (lane == 0) { bo.end_bit = r.pos; bo.count = dbuf_count; bo.orig = orig; bo.err = err; outs[c] = bo; }
 }
 
@@ -598,8 +727,15 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   if (rc) { cleanup(); return rc; }
   std::vector<BlockOut> bos(ncand);
   if (ncand) {
-    hipLaunchKernelGGL(bz_decode_block, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
+    static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
+    if (v1) hipLaunchKernelGGL(bz_decode_block<1>, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
+    else hipLaunchKernelGGL(bz_decode_block<2>, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
     if (hipMemcpyAsync(bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
+    if (getenv("CJS_DEBUG")) {
+      uint64_t clk[8];
+      if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess)
+        fprintf(stderr, "[cjs dec] candidate 0: header+selectors+lengths %.1f us, tables %.1f us, symbol loop %.1f us\n", (clk[1] - clk[0]) / 100.0, (clk[2] - clk[1]) / 100.0, (clk[3] - clk[2]) / 100.0);
+    }
   }
   // chain walk (Bunzip.decode :1776-1794)
   auto find = [&](uint64_t bit) -> long {
