@@ -239,6 +239,7 @@ __device__ SpecOut spec_boundary(const uint8_t* __restrict__ in, uint64_t N, uin
   return o;
 }
 
+__device__ uint64_t g_walk_dbg[8];     // CJS_DEBUG: [0] speculative rounds [1] serial steps [2],[3] their 100 MHz ticks
 __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in, uint64_t N, uint32_t cap, uint32_t Tn,
                                                  const uint64_t* __restrict__ run_start_in, const uint64_t* __restrict__ next_bnd,
                                                  const uint64_t* __restrict__ gt, const uint16_t* __restrict__ subpre, const uint8_t* __restrict__ dmod,
@@ -250,7 +251,9 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
   uint64_t s = 0;
   uint32_t k = 0;
   bool done = false;
+  uint64_t dbg_n[2] = {0, 0}, dbg_t[2] = {0, 0};
   while (s < N && k < max_blocks && !done) {
+    const uint64_t t_in = wall_clock64();
     // ---- speculative rounds: only from a run boundary
     if (s == 0 || in[s] != in[s - 1]) {
       // G(s): tile prefix + in-tile prefix (one cooperative tile evaluation)
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
         else { k += m + 1; s = e_m; }
       } else { k += 1024; s = spec_e[1023]; }
       __syncthreads();
+      dbg_n[0]++; dbg_t[0] += wall_clock64() - t_in;
       continue;
     }
     // end of the run containing s
@@ -348,9 +352,10 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
     }
     k++;
     s = e;
+    dbg_n[1]++; dbg_t[1] += wall_clock64() - t_in;
     if (len < cap) break;
   }
-  if (threadIdx.x == 0) *nblocks_out = k;
+  if (threadIdx.x == 0) { *nblocks_out = k; g_walk_dbg[0] = dbg_n[0]; g_walk_dbg[1] = dbg_n[1]; g_walk_dbg[2] = dbg_t[0]; g_walk_dbg[3] = dbg_t[1]; }
 }
 
 // ---- R: materialise the RLE1 bytes of every block (grid = input tiles)
@@ -636,6 +641,12 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32
   CJS_HIP_TRY(hipMemcpyAsync(w.h_n, w.nblocks, 4, hipMemcpyDeviceToHost, s));
   CJS_HIP_TRY(hipStreamSynchronize(s));
   *nblocks_host = w.h_n[0];
+  if (getenv("CJS_DEBUG")) {
+    uint64_t d[8];
+    if (hipMemcpyFromSymbol(d, HIP_SYMBOL(g_walk_dbg), sizeof d) == hipSuccess)
+      fprintf(stderr, "[cjs rle] boundary walk: %llu speculative rounds %.1f us, %llu serial steps %.1f us, %u blocks\n", (unsigned long long)d[0], d[2] / 100.0,
+              (unsigned long long)d[1], d[3] / 100.0, w.h_n[0]);
+  }
   return 0;
 }
 
