@@ -204,41 +204,91 @@ __device__ void walk_tile_eval(const uint8_t* __restrict__ in, uint64_t N, uint6
 
 // ---- W: block boundaries.  ONE workgroup, serial over blocks.
 // Speculative boundary search: from a block start s0 that coincides with a run boundary (fresh chunking == global
-// chunking), the next boundaries are where G reaches G(s0) + j*cap.  Lane j looks its boundary up on its own
-// (binary search on G_tile, then the subtile table, then <= 256 bytes serially).  A boundary is "clean" when G hits
+// chunking), the next boundaries are where G reaches G(s0) + j*cap.  Group j (32 lanes) looks boundary j up
+// (search on G_tile, then the subtile table, then the <= 256 bytes of the subtile).  A boundary is "clean" when G hits
 // the target exactly and the next block again starts on a run boundary; blocks up to the first unclean boundary
 // are exact, the unclean one is resolved by one serial step of the general rule, and speculation resumes.
 struct SpecOut { uint64_t e; uint32_t clean; uint32_t eof; uint32_t len_last; };
-__device__ SpecOut spec_boundary(const uint8_t* __restrict__ in, uint64_t N, uint32_t Tn, const uint64_t* __restrict__ gt,
-                                 const uint16_t* __restrict__ subpre, const uint8_t* __restrict__ dmod, uint64_t target, uint64_t prev_target) {
+// The search for ONE target is done by a group of 32 lanes: 32-ary search on G_tile (3 dependent loads instead of the
+// 15 of a binary search), one ballot over the 16 subtile prefixes, and the 256-byte subtile scanned 8 bytes per lane with two
+// 32-lane scans (last run start, emitted-byte prefix).  A round of the walk costs a handful of memory round trips.
+__device__ SpecOut spec_boundary_group(const uint8_t* __restrict__ in, uint64_t N, uint32_t Tn, const uint64_t* __restrict__ gt,
+                                       const uint16_t* __restrict__ subpre, const uint8_t* __restrict__ dmod, uint64_t target, uint64_t prev_target) {
+  const uint32_t l = threadIdx.x & 31u, hs = threadIdx.x & 32u;        // lane in the group; the group's half of the wave ballot
   SpecOut o; o.e = N; o.clean = 0; o.eof = 0; o.len_last = 0;
-  if (gt[Tn] < target) { o.eof = 1; o.len_last = gt[Tn] > prev_target ? (uint32_t)(gt[Tn] - prev_target) : 0u; return o; }
-  uint32_t lo = 0, hi = Tn;                       // last tile with gt[t] < target   (gt[0] = 0 < target)
-  while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (gt[mid] < target) lo = mid; else hi = mid; }
-  const uint64_t need = target - gt[lo];          // 1 .. tile count
-  uint32_t sb = 0;
-  for (uint32_t q = 1; q < 16; q++) if ((uint64_t)subpre[(size_t)lo * 16 + q] < need) sb = q;
-  uint64_t p = (uint64_t)lo * RT + (uint64_t)sb * 256;
-  uint64_t acc = subpre[(size_t)lo * 16 + sb];
-  uint32_t dm = dmod[(size_t)lo * 16 + sb];
-  uint8_t prev = in[p];
-  for (uint32_t q = 0; q < 256 && p < N; q++, p++) {
-    const uint8_t c = in[p];
-    if (q) dm = (c != prev) ? 0u : (dm + 1u == 255u ? 0u : dm + 1u);
-    prev = c;
-    acc += dm < 3 ? 1u : dm == 3 ? 2u : 0u;
-    if (acc >= need) {
-      o.e = p + 1;
-      const bool exact = acc == need;
-      const bool next_fresh = p + 1 >= N || in[p + 1] != c;
-      o.clean = exact && next_fresh;
-      return o;
-    }
+  const uint64_t gtot = gt[Tn];
+  if (gtot < target) { o.eof = 1; o.len_last = gtot > prev_target ? (uint32_t)(gtot - prev_target) : 0u; return o; }
+  uint32_t lo = 0, hi = Tn;                       // gt[lo] < target <= gt[hi]
+  while (hi - lo > 1) {
+    const uint32_t step = (hi - lo + 31u) / 32u;
+    const uint64_t idx = (uint64_t)lo + (uint64_t)l * step;
+    const bool pred = idx < hi && gt[idx] < target;
+    const uint32_t cnt = (uint32_t)__builtin_popcount((uint32_t)(__ballot(pred) >> hs));     // ones are a prefix (gt is monotone), lane 0 is one
+    const uint32_t nlo = lo + (cnt - 1u) * step;
+    hi = nlo + step < hi ? nlo + step : hi;
+    lo = nlo;
   }
-  o.e = p;             // not reached (tables inconsistent): treated as unclean at this position
+  const uint64_t need = target - gt[lo];          // 1 .. tile count
+  const uint32_t sp = l < 16 ? (uint32_t)subpre[(size_t)lo * 16 + l] : 0u;
+  const bool pq = l < 16 && (l == 0 || (uint64_t)sp < need);
+  const uint32_t sb = (uint32_t)__builtin_popcount((uint32_t)(__ballot(pq) >> hs)) - 1u;
+  const uint32_t acc0 = (uint32_t)__shfl((int)sp, (int)sb, 32);
+  const uint32_t d0 = dmod[(size_t)lo * 16 + sb];
+  const uint64_t p0 = (uint64_t)lo * RT + (uint64_t)sb * 256;
+  const uint64_t pb = p0 + 8u * l;
+  uint8_t b[8];
+  if (pb + 8 <= N && (((uintptr_t)(in + pb)) & 7u) == 0) {
+    const uint64_t v = *reinterpret_cast<const uint64_t*>(in + pb);
+#pragma unroll
+    for (int t = 0; t < 8; t++) b[t] = (uint8_t)(v >> (8 * t));
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; t++) b[t] = pb + t < N ? in[pb + t] : 0;
+  }
+  const uint32_t prevb = (uint32_t)__shfl_up((int)b[7], 1, 32);
+  uint32_t rsmask = 0; int my_last = -1;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const uint32_t i = 8u * l + t;
+    const uint32_t pv = t ? b[t - 1] : prevb;
+    if (i > 0 && pb + t < N && b[t] != pv) { rsmask |= 1u << t; my_last = (int)i; }
+  }
+  int incl = my_last;
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) { const int x = __shfl_up(incl, d, 32); if ((int)l >= d && x > incl) incl = x; }
+  int rs = __shfl_up(incl, 1, 32);
+  if (l == 0) rs = -1;
+  uint32_t cs[8], sum = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const uint32_t i = 8u * l + t;
+    if ((rsmask >> t) & 1u) rs = (int)i;
+    uint32_t dm = rs >= 0 ? i - (uint32_t)rs : d0 + i;
+    dm = dm >= 255u ? dm - 255u : dm;                                   // d0 <= 254, i <= 255: one subtract is "% 255"
+    dm = dm >= 255u ? dm - 255u : dm;
+    const uint32_t c = pb + t < N ? (dm < 3 ? 1u : dm == 3 ? 2u : 0u) : 0u;
+    sum += c; cs[t] = sum;
+  }
+  uint32_t incl2 = sum;
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl2, d, 32); if ((int)l >= d) incl2 += x; }
+  const uint32_t excl = incl2 - sum;
+  const uint32_t rel = (uint32_t)(need - acc0);                          // >= 1
+  const uint32_t hm = (uint32_t)(__ballot(incl2 >= rel) >> hs);
+  if (!hm) { o.e = p0 + 256 < N ? p0 + 256 : N; return o; }             // not reached (tables inconsistent): unclean
+  const int fl = __builtin_ctz(hm);
+  int tt = 8; uint32_t accv = 0, cv = 0;
+#pragma unroll
+  for (int t = 7; t >= 0; t--) if (excl + cs[t] >= rel) { tt = t; accv = excl + cs[t]; cv = b[t]; }
+  tt = __shfl(tt, fl, 32); accv = (uint32_t)__shfl((int)accv, fl, 32); cv = (uint32_t)__shfl((int)cv, fl, 32);
+  const uint64_t pe = p0 + 8u * (uint32_t)fl + (uint32_t)tt;
+  o.e = pe + 1;
+  const bool next_fresh = pe + 1 >= N || in[pe + 1] != (uint8_t)cv;
+  o.clean = (accv == rel) && next_fresh;
   return o;
 }
 
+constexpr uint32_t NSPEC = 32;        // boundaries speculated per round: one 32-lane group each
 __device__ uint64_t g_walk_dbg[8];     // CJS_DEBUG: [0] speculative rounds [1] serial steps [2],[3] their 100 MHz ticks
 __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in, uint64_t N, uint32_t cap, uint32_t Tn,
                                                  const uint64_t* __restrict__ run_start_in, const uint64_t* __restrict__ next_bnd,
@@ -251,7 +301,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
   uint64_t s = 0;
   uint32_t k = 0;
   bool done = false;
-  uint64_t dbg_n[2] = {0, 0}, dbg_t[2] = {0, 0};
+  uint64_t dbg_n[2] = {0, 0}, dbg_t[2] = {0, 0}, dbg_p[3] = {0, 0, 0};
   while (s < N && k < max_blocks && !done) {
     const uint64_t t_in = wall_clock64();
     // ---- speculative rounds: only from a run boundary
@@ -261,26 +311,30 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
       uint64_t fp; uint32_t below;
       walk_tile_eval(in, N, (uint64_t)t0 * RT, run_start_in[t0], 0, NONE64, s, smem, sh64, fp, below);
       const uint64_t G0 = gt[t0] + below;
-      const uint32_t j = threadIdx.x;
-      if (j == 0) spec_first_bad = 1024;
+      const uint64_t t_a = wall_clock64(); dbg_p[0] += t_a - t_in;
+      const uint32_t j = threadIdx.x >> 5;               // group = speculated boundary
+      if (threadIdx.x == 0) spec_first_bad = NSPEC;
       __syncthreads();
-      SpecOut so = spec_boundary(in, N, Tn, gt, subpre, dmod, G0 + (uint64_t)(j + 1) * cap, G0 + (uint64_t)j * cap);
-      spec_e[j] = so.e;
-      if (!so.clean || so.eof) atomicMin(&spec_first_bad, j);
+      SpecOut so = spec_boundary_group(in, N, Tn, gt, subpre, dmod, G0 + (uint64_t)(j + 1) * cap, G0 + (uint64_t)j * cap);
+      const bool lead = (threadIdx.x & 31u) == 0;
+      if (lead) spec_e[j] = so.e;
+      const uint64_t t_b = wall_clock64(); dbg_p[1] += t_b - t_a;
+      if (lead && (!so.clean || so.eof)) atomicMin(&spec_first_bad, j);
       __syncthreads();
+      dbg_p[2] += wall_clock64() - t_b;
       const uint32_t m = spec_first_bad;                    // boundaries 0..m-1 are clean; boundary m is EOF or unclean
       // blocks k+j for j <= m (block j spans (boundary j-1, boundary j]); the one ending at boundary m is still exact
-      if (j <= m && j < 1024 && k + j < max_blocks) {
+      if (lead && j <= m && k + j < max_blocks) {
         const uint64_t bs = j == 0 ? s : spec_e[j - 1];
         RleBlock bd; bd.s = bs; bd.r_end = bs; bd.base = 0; bd.Gr = G0 + (uint64_t)j * cap;
         bool emit = true;
         if (so.eof) { bd.e = N; bd.len = so.len_last; emit = so.len_last > 0 && bs < N; }
         else { bd.e = so.e; bd.len = cap; }
-        if (j < m || (j == m && m < 1024)) { if (emit) blocks[k + j] = bd; }
+        if (j < m || (j == m && m < NSPEC)) { if (emit) blocks[k + j] = bd; }
       }
       __syncthreads();
       // advance: count emitted blocks
-      if (m < 1024) {
+      if (m < NSPEC) {
         // boundary m: EOF (stream ends) or unclean (continue with the general rule from its end)
         const unsigned long long e_m = spec_e[m];
         // was block m emitted?  eof with zero length -> not
@@ -288,7 +342,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
         const bool eof_m = gt[Tn] < tgt_prev + cap;
         if (eof_m) { const bool has = gt[Tn] > tgt_prev && (m == 0 ? s : spec_e[m - 1]) < N; k += m + (has ? 1u : 0u); done = true; }
         else { k += m + 1; s = e_m; }
-      } else { k += 1024; s = spec_e[1023]; }
+      } else { k += NSPEC; s = spec_e[NSPEC - 1]; }
       __syncthreads();
       dbg_n[0]++; dbg_t[0] += wall_clock64() - t_in;
       continue;
@@ -355,7 +409,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
     dbg_n[1]++; dbg_t[1] += wall_clock64() - t_in;
     if (len < cap) break;
   }
-  if (threadIdx.x == 0) { *nblocks_out = k; g_walk_dbg[0] = dbg_n[0]; g_walk_dbg[1] = dbg_n[1]; g_walk_dbg[2] = dbg_t[0]; g_walk_dbg[3] = dbg_t[1]; }
+  if (threadIdx.x == 0) { *nblocks_out = k; g_walk_dbg[0] = dbg_n[0]; g_walk_dbg[1] = dbg_n[1]; g_walk_dbg[2] = dbg_t[0]; g_walk_dbg[3] = dbg_t[1]; g_walk_dbg[4] = dbg_p[0]; g_walk_dbg[5] = dbg_p[1]; g_walk_dbg[6] = dbg_p[2]; }
 }
 
 // ---- R: materialise the RLE1 bytes of every block (grid = input tiles)
@@ -644,8 +698,8 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32
   if (getenv("CJS_DEBUG")) {
     uint64_t d[8];
     if (hipMemcpyFromSymbol(d, HIP_SYMBOL(g_walk_dbg), sizeof d) == hipSuccess)
-      fprintf(stderr, "[cjs rle] boundary walk: %llu speculative rounds %.1f us, %llu serial steps %.1f us, %u blocks\n", (unsigned long long)d[0], d[2] / 100.0,
-              (unsigned long long)d[1], d[3] / 100.0, w.h_n[0]);
+      fprintf(stderr, "[cjs rle] boundary walk: %llu speculative rounds %.1f us, %llu serial steps %.1f us, %u blocks; thread 0 of the rounds: tile eval %.1f us, own search %.1f us, wait for the slowest lane %.1f us\n", (unsigned long long)d[0], d[2] / 100.0,
+              (unsigned long long)d[1], d[3] / 100.0, w.h_n[0], d[4] / 100.0, d[5] / 100.0, d[6] / 100.0);
   }
   return 0;
 }
