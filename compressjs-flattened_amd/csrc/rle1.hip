@@ -28,6 +28,20 @@ __device__ __forceinline__ uint32_t emitted_fresh(uint64_t m) {   // output byte
   return (uint32_t)(5 * q) + (r < 4 ? r : 5u);
 }
 
+// 16 consecutive input bytes of one lane as ONE 16-byte load when the address allows it (consecutive lanes then read
+// consecutive 16-byte words: a wave covers 1 KiB per instruction instead of touching 16 lines sixteen times)
+__device__ __forceinline__ void load16(const uint8_t* __restrict__ in, uint64_t N, uint64_t p0, uint8_t (&b)[16]) {
+  if (p0 + 16 <= N && (((uintptr_t)(in + p0)) & 15u) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(in + p0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 16; j++) b[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++) b[j] = p0 + j < N ? in[p0 + j] : 0;
+  }
+}
+
 // Per-thread view of ITEMS consecutive positions starting at p0: boundary flags and the run start
 // governing the first position.  BLOCK threads cover BLOCK*ITEMS positions from tile_start.
 // carry = start of the run that contains tile_start when tile_start itself is not a boundary.
@@ -39,10 +53,14 @@ __device__ __forceinline__ void run_starts(const uint8_t* __restrict__ in, uint6
   if (p0 > 0 && p0 - 1 < N) prev = in[p0 - 1];
   bmask = 0;
   uint32_t last = 0;     // (tile-relative index of my last boundary)+1
+  if (ITEMS == 16) load16(in, N, p0, reinterpret_cast<uint8_t (&)[16]>(b));
+  else {
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) b[j] = p0 + j < N ? in[p0 + j] : 0;
+  }
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     const uint64_t p = p0 + j;
-    b[j] = p < N ? in[p] : 0;
     const bool bd = p < N && (p == 0 || b[j] != prev);
     if (bd) { bmask |= 1u << j; last = (uint32_t)(p - tile_start) + 1u; }
     prev = b[j];
@@ -62,10 +80,13 @@ __global__ __launch_bounds__(256) void rle_tile_summary(const uint8_t* __restric
   uint8_t prev = 0;
   if (p0 > 0 && p0 - 1 < N) prev = in[p0 - 1];
   uint32_t first = 0xFFFFFFFFu, last = 0;
+  uint8_t b[16];
+  load16(in, N, p0, b);
+#pragma unroll
   for (int j = 0; j < 16; j++) {
     const uint64_t p = p0 + j;
     if (p < N) {
-      const uint8_t c = in[p];
+      const uint8_t c = b[j];
       if (p == 0 || c != prev) { const uint32_t rel = (uint32_t)(p - tile_start); if (first == 0xFFFFFFFFu) first = rel; last = rel + 1; }
       prev = c;
     }
