@@ -41,6 +41,14 @@ BWT_INPUTS = {
     "random2sym": (recipes.build({"kind": "xorshift", "n": 150000, "seed": 4242, "mask": 1, "add": 48}), 150000),
     "textgen_multi": (recipes.build({"kind": "textgen", "n": 1000000, "seed": 1}), 99981),
     "textgen_900k": (recipes.build({"kind": "textgen", "n": 1000000, "seed": 3}), 899981),
+    # a long periodic stretch inside text: eight groups of 25,000 suffixes that stay unresolved for ~15 doubling rounds
+    # (compact -> radix -> scatter-back path beside the in-LDS tile sort), text groups around them
+    "text_plus_periodic": (recipes.build({"kind": "concat", "parts": [
+        {"kind": "textgen", "n": 600000, "seed": 5}, {"kind": "repeat", "unit_hex": "6162636465666768", "n": 200000},
+        {"kind": "textgen", "n": 99981, "seed": 6}]}), 899981),
+    # medium groups: a 2000-byte page repeated 150 times with one changed byte per copy (groups of ~150, then splits)
+    "page_repeats": (np.concatenate([np.concatenate([recipes.build({"kind": "textgen", "n": 2000, "seed": 9}),
+                                                     np.array([65 + (i % 26)], dtype=np.uint8)]) for i in range(150)]), 300150),
     "sample3": (recipes.build({"kind": "file", "name": "sample3.ref"}), 120244),
     "sample1": (recipes.build({"kind": "file", "name": "sample1.ref"}), 98696),
 }
