@@ -262,8 +262,11 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
 #pragma unroll
       for (int b = 0; b < 4; b++) L |= (uint32_t)S.sym_to_byte[4 * lane + b] << (8 * b);
       uint32_t outb = 0, obase = 0;
-      int32_t run_pos = 0; long long run_t = 0;
-      uint32_t selector = 0; int sym_left = 0, g = 0;
+      // a RUNA/RUNB run: run_t = sum of (sym+1) << (index in the run).  20 run symbols already give run_t >= 2^20 - 1 >
+      // dbufSize, which the reference rejects when the run ends (:1636) - so the run is cut there with the same error
+      uint32_t run_bit = 0, run_t = 0;
+      uint32_t selector = 0, sym_left = 0; int g = 0;
+      const int lane4m1 = 4 * lane - 1;
       bool done = false;
       while (!done && !err) {
         if (sym_left == 0) {
@@ -283,13 +286,11 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
           e = S.fast[g][x];
         }
         uint32_t idx = 0;
-        while (idx < 64 && sym_left > 0) {
-          const uint32_t ee = __builtin_amdgcn_readlane(e, idx);
-          uint32_t next_sym, len;
-          if (ee == 0x1F) { err = CJS_E_DATA_ERROR; break; }
-          if (ee) { next_sym = ee >> 5; len = ee & 31u; }
-          else {                                               // long code: the reference's bit-by-bit rule
-            const uint64_t p0 = pos + idx;
+        do {
+          uint32_t ee = __builtin_amdgcn_readlane(e, idx);
+          if (__builtin_expect(ee == 0u || ee == 0x1Fu, 0)) {
+            if (ee) { err = CJS_E_DATA_ERROR; break; }
+            const uint64_t p0 = pos + idx;                     // long code: the reference's bit-by-bit rule
             int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);
             const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
             long long j = bw.peek(p0, i);
@@ -301,37 +302,43 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
             if (err) break;
             j -= (long long)__builtin_amdgcn_readfirstlane(S.base[g][i]);
             if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
-            next_sym = __builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]); len = (uint32_t)i;
+            ee = (__builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]) << 5) | (uint32_t)i;
           }
-          idx += len; sym_left--;
+          const uint32_t next_sym = ee >> 5;
+          idx += ee & 31u; sym_left--;
           if (next_sym <= 1) {                                 // RUNA / RUNB
-            if (!run_pos) { run_pos = 1; run_t = 0; }
-            run_t += next_sym == 0 ? (long long)run_pos : 2 * (long long)run_pos;
-            run_pos = (int32_t)((uint32_t)run_pos << 1);
+            run_t += (next_sym + 1u) << run_bit;
+            if (++run_bit >= 20) { err = CJS_E_DATA_ERROR; break; }
             continue;
           }
-          if (run_pos) {
-            run_pos = 0;
-            if ((long long)dbuf_count + run_t > (long long)dbuf_size) { err = CJS_E_DATA_ERROR; break; }
+          if (run_bit) {
+            run_bit = 0;
+            if (dbuf_count + run_t > dbuf_size) { err = CJS_E_DATA_ERROR; break; }
             const uint8_t uc = (uint8_t)(__builtin_amdgcn_readlane(L, 0) & 0xFFu);
             if ((uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;       // pending singles first
-            for (long long q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
-            dbuf_count += (uint32_t)run_t;
+            for (uint32_t q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
+            dbuf_count += run_t;
             obase = dbuf_count;
+            run_t = 0;
           }
           if (next_sym > sym_total) { done = true; break; }     // EOB
           if (dbuf_count >= dbuf_size) { err = CJS_E_DATA_ERROR; break; }
-          const uint32_t k = next_sym - 1, q = k >> 2, rb = k & 3u;
-          const uint32_t v = (__builtin_amdgcn_readlane(L, q) >> (8u * rb)) & 0xFFu;
-          const uint32_t up = __builtin_amdgcn_update_dpp(0u, L, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-          const uint32_t shifted = (L << 8) | (lane == 0 ? v : up >> 24);
-          const uint32_t m = (uint32_t)lane < q ? 0xFFFFFFFFu : (uint32_t)lane == q ? (rb == 3 ? 0xFFFFFFFFu : ((1u << (8u * (rb + 1u))) - 1u)) : 0u;
+          // move to front: list position 4*lane+b is byte b of L.  (A branch-free variant that also ran this block for
+          // run symbols with k = 0 was slower, 159 vs 130 ms: for a lone wave the vector instructions cost more than the branch.)
+          const uint32_t k = next_sym - 1;
+          const uint32_t v = (__builtin_amdgcn_readlane(L, k >> 2) >> (8u * (k & 3u))) & 0xFFu;
+          const uint32_t vv = v << 24;
+          const uint32_t up = __builtin_amdgcn_update_dpp(vv, L, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 keeps vv
+          const uint32_t shifted = __builtin_amdgcn_alignbit(L, up, 24);                                     // (L << 8) | (up >> 24)
+          int nb = (int)k - lane4m1;                                                                          // bytes of this lane that move
+          nb = nb < 0 ? 0 : nb > 4 ? 4 : nb;
+          const uint32_t m = (uint32_t)((1ull << (8 * nb)) - 1ull);
           L = (shifted & m) | (L & ~m);
           const uint32_t slot = dbuf_count - obase;
           outb = (uint32_t)lane == slot ? v : outb;
           dbuf_count++;
           if (slot == 63) { tt[obase + lane] = (uint8_t)outb; obase = dbuf_count; }
-        }
+        } while (idx < 64 && sym_left);
         pos += idx;
       }
       if (!err && (uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;
