@@ -130,25 +130,15 @@ struct BitWin {
   }
 };
 
-__device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
-#define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
-template <int V>
-__global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand,
-                                                      uint32_t dbuf_size, uint8_t* __restrict__ tt_all, uint32_t* __restrict__ hist_all,
-                                                      BlockOut* __restrict__ outs) {
-  __shared__ DecShared S;
-  const uint32_t c = blockIdx.x;
-  if (c >= ncand) return;
-  const int lane = lane_id();
-  BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
-  if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
-  uint8_t* tt = tt_all + (size_t)c * dbuf_size;
-  BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
+// Block header, selector list, code lengths (lane 0, serial) and the decode tables (whole wave).  Executed by ONE wave;
+// the results are wave-uniform scalars.  Returns 0 or a CJS_E_* code.
+__device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint32_t& crc, uint32_t& orig, uint32_t& sym_total,
+                            uint32_t& group_count, uint32_t& n_sel) {
   int err = 0;
-  uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0;
-  DEC_MARK(0);
+  sym_total = 0; group_count = 0; n_sel = 0; orig = 0;
+  const int lane = lane_id();
   if (lane == 0) {                                           // header (:1440-1493)
-    bo.crc = r.get(16) << 16; bo.crc |= r.get(16);
+    crc = r.get(16) << 16; crc |= r.get(16);
     if (r.get(1)) err = CJS_E_OBSOLETE_INPUT;
     orig = r.get(24);
     if (!err && orig > dbuf_size) err = CJS_E_DATA_ERROR;
@@ -190,7 +180,6 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
       }
     }
   }
-  DEC_MARK(1);
   // lane 0's results become wave-uniform scalars (readfirstlane, not a shuffle: the compiler must KNOW they are uniform,
   // or the whole symbol loop is compiled as divergent code under exec masks)
   err = __builtin_amdgcn_readfirstlane(err);
@@ -242,6 +231,29 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
     for (int i = lane; i < 256; i += 64) { S.byte_count[i] = 0; S.mtf[i] = (uint8_t)i; }
   }
   __builtin_amdgcn_wave_barrier();
+  crc = __builtin_amdgcn_readfirstlane(crc);
+  orig = __builtin_amdgcn_readfirstlane(orig);
+  r.pos = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
+  return err;
+}
+
+__device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
+#define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
+template <int V>
+__global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand,
+                                                      uint32_t dbuf_size, uint8_t* __restrict__ tt_all, uint32_t* __restrict__ hist_all,
+                                                      BlockOut* __restrict__ outs) {
+  __shared__ DecShared S;
+  const uint32_t c = blockIdx.x;
+  if (c >= ncand) return;
+  const int lane = lane_id();
+  BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
+  if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
+  uint8_t* tt = tt_all + (size_t)c * dbuf_size;
+  BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
+  uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0;
+  DEC_MARK(0);
+  int err = dec_prologue(S, r, dbuf_size, bo.crc, orig, sym_total, group_count, n_sel);
   DEC_MARK(2);
   uint32_t dbuf_count = 0;
   r.pos = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
@@ -421,6 +433,211 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
   err = __shfl(err, 0, 64);
   if (V != 2 && !err) for (int i = lane; i < 256; i += 64) hist_all[(size_t)c * 256 + i] = S.byte_count[i];
   if (lane == 0) { bo.end_bit = r.pos; bo.count = dbuf_count; bo.orig = orig; bo.err = err; outs[c] = bo; }
+}
+
+// ---------------------------------------------------------------- 2b. the same decode as a two-wave pipeline
+// A lone wave issues about one instruction every 8 cycles and a block is one dependent chain of ~650 k symbols, so the
+// chain is cut in two stages that run on different SIMDs of the CU:
+//   wave 0 (producer): Huffman codes -> symbols (table lookups for 64 bit positions at once + readlane chain, as above);
+//                      the symbols of a round are collected in a register (one lane each) and leave as ONE LDS store;
+//   wave 1 (consumer): RUNA/RUNB + move-to-front + output bytes, reading up to 64 symbols per LDS load.
+// They share a ring of symbols in LDS; the cursors are workgroup-scope atomics.  Every wait loop also watches the
+// other side's stop flag, so both waves always reach the final barrier.
+constexpr uint32_t PIPE_RING = 2048;          // symbols
+constexpr uint32_t PIPE_EOB = 0xFFFFu;
+struct PipeShared {
+  uint16_t ring[PIPE_RING];
+  uint32_t wr, rd;                            // symbols produced / consumed
+  uint32_t stop;                              // bit 0: producer finished (EOB or error), bit 1: consumer aborted
+  int32_t perr, cerr;                         // error codes of the two sides
+  uint32_t sym_total, orig, crc, count;
+  uint64_t end_bit;
+};
+__global__ __launch_bounds__(128) void bz_decode_block_pipe(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand,
+                                                            uint32_t dbuf_size, uint8_t* __restrict__ tt_all, BlockOut* __restrict__ outs) {
+  __shared__ DecShared S;
+  __shared__ PipeShared P;
+  const uint32_t c = blockIdx.x;
+  if (c >= ncand) return;
+  const int lane = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (cands[c].kind != 0) {
+    if (threadIdx.x == 0) { BlockOut bo; bo.end_bit = cands[c].bit + 48; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0; outs[c] = bo; }
+    return;
+  }
+  uint8_t* tt = tt_all + (size_t)c * dbuf_size;
+  uint32_t group_count = 0, n_sel = 0;
+  uint64_t pos = 0;
+  if (wv == 0) {
+    BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
+    uint32_t crc = 0, orig = 0, sym_total = 0;
+    const int err = dec_prologue(S, r, dbuf_size, crc, orig, sym_total, group_count, n_sel);
+    pos = r.pos;
+    if (lane == 0) { P.wr = 0; P.rd = 0; P.stop = 0; P.perr = err; P.cerr = 0; P.sym_total = sym_total; P.orig = orig; P.crc = crc; P.count = 0; P.end_bit = r.pos; }
+  }
+  __syncthreads();
+  const int err0 = __builtin_amdgcn_readfirstlane(P.perr);
+  const uint32_t sym_total = __builtin_amdgcn_readfirstlane(P.sym_total);
+  if (!err0) {
+    if (wv == 0) {
+      // ---------------- producer
+      BitWin bw{in, n, 0, 0, 0};
+      bw.init(pos, lane);
+      int err = 0;
+      uint32_t selector = 0, sym_left = 0, wr = 0, rd_seen = 0; int g = 0;
+      uint32_t dbg_full = 0, dbg_rounds = 0;
+      const uint64_t t_p0 = wall_clock64();
+      bool done = false;
+      while (!done && !err) {
+        if (sym_left == 0) {
+          sym_left = 50;
+          if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
+          g = __builtin_amdgcn_readfirstlane((int)S.selectors[selector++]);
+          if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
+        }
+        bw.ensure(pos, lane);
+        uint32_t e;
+        {
+          const uint32_t d = (uint32_t)((pos >> 5) - bw.base);
+          const uint32_t w0 = bw.word(d), w1 = bw.word(d + 1), w2 = bw.word(d + 2), w3 = bw.word(d + 3);
+          const uint32_t o = (uint32_t)(pos & 31) + (uint32_t)lane, wi = o >> 5;
+          const uint32_t hi = wi == 0 ? w0 : wi == 1 ? w1 : w2, lo = wi == 0 ? w1 : wi == 1 ? w2 : w3;
+          const uint32_t x = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31)) >> 54);
+          e = S.fast[g][x];
+        }
+        uint32_t idx = 0, cnt = 0, symv = 0;
+        do {
+          uint32_t ee = __builtin_amdgcn_readlane(e, idx);
+          if (__builtin_expect(ee == 0u || ee == 0x1Fu, 0)) {
+            if (ee) { err = CJS_E_DATA_ERROR; break; }
+            const uint64_t p0 = pos + idx;                     // long code: the reference's bit-by-bit rule
+            int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);
+            const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
+            long long j = bw.peek(p0, i);
+            for (;; i++) {
+              if (i > mx) { err = CJS_E_DATA_ERROR; break; }
+              if (j <= (long long)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
+              j = (j << 1) | bw.peek(p0 + i, 1);
+            }
+            if (err) break;
+            j -= (long long)__builtin_amdgcn_readfirstlane(S.base[g][i]);
+            if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
+            ee = (__builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]) << 5) | (uint32_t)i;
+          }
+          uint32_t sym = ee >> 5;
+          idx += ee & 31u; sym_left--;
+          if (sym > sym_total) { sym = PIPE_EOB; done = true; }
+          symv = (uint32_t)lane == cnt ? sym : symv;               // lane cnt keeps the symbol (v_writelane would need m0)
+          cnt++;
+        } while (!done && idx < 64 && sym_left);
+        pos += idx;
+        if (cnt) {
+          // room for this round?  (the consumer's cursor is re-read only when the cached one says "full")
+          while (wr + cnt - rd_seen > PIPE_RING) {
+            rd_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.rd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));     // uniform, and known to be
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & 2u) { done = true; cnt = 0; break; }
+            if (wr + cnt - rd_seen > PIPE_RING) { dbg_full++; __builtin_amdgcn_s_sleep(2); }
+          }
+          if ((uint32_t)lane < cnt) P.ring[(wr + lane) & (PIPE_RING - 1)] = (uint16_t)symv;
+          wr += cnt; dbg_rounds++;
+          if (lane == 0) __hip_atomic_store(&P.wr, wr, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      if (lane == 0 && blockIdx.x == 0) { g_dec_clk[4] = dbg_full; g_dec_clk[5] = dbg_rounds; g_dec_clk[6] = wall_clock64() - t_p0; g_dec_clk[7] = wr; }
+      if (lane == 0) {
+        P.perr = err;
+        P.end_bit = pos > n * 8 ? n * 8 : pos;
+        __hip_atomic_fetch_or(&P.stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {
+      // ---------------- consumer
+      uint32_t L = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) L |= (uint32_t)S.sym_to_byte[4 * lane + b] << (8 * b);
+      const int lane4m1 = 4 * lane - 1;
+      uint32_t outb = 0, obase = 0, dbuf_count = 0, run_bit = 0, run_t = 0, rd = 0;
+      uint32_t dbg_empty = 0, dbg_batches = 0;
+      const uint64_t t_c0 = wall_clock64();
+      int err = 0;
+      bool done = false;
+      while (!done && !err) {
+        const uint32_t wr = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.wr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (wr == rd) {
+          if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) & 1u) {
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.wr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == rd) break;    // producer stopped without EOB (its error)
+            continue;
+          }
+          dbg_empty++;
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        dbg_batches++;
+        const uint32_t navail = wr - rd, nb_ = navail < 64u ? navail : 64u;
+        const uint32_t symv = (uint32_t)lane < nb_ ? (uint32_t)P.ring[(rd + lane) & (PIPE_RING - 1)] : 0u;
+        // structured control flow only (no break/continue): every early exit would make the compiler thread a state
+        // variable through the loop nest, which costs this lone wave more than the work itself
+        uint32_t stopc = 0;                                    // 1 = EOB, 2 = data error
+        dbuf_count = __builtin_amdgcn_readfirstlane(dbuf_count); obase = __builtin_amdgcn_readfirstlane(obase);      // (tell the compiler: uniform)
+        run_t = __builtin_amdgcn_readfirstlane(run_t); run_bit = __builtin_amdgcn_readfirstlane(run_bit);
+        for (uint32_t rr = 0; rr < nb_ && !stopc; rr++) {
+          const uint32_t next_sym = __builtin_amdgcn_readlane(symv, rr);
+          if (next_sym <= 1) {                                 // RUNA / RUNB
+            run_t += (next_sym + 1u) << run_bit;
+            run_bit++;
+            stopc = run_bit >= 20 ? 2u : 0u;
+          } else {
+            if (run_bit) {
+              run_bit = 0;
+              if (dbuf_count + run_t > dbuf_size) stopc = 2;
+              else {
+                const uint8_t uc = (uint8_t)(__builtin_amdgcn_readlane(L, 0) & 0xFFu);
+                if ((uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;       // pending singles first
+                for (uint32_t q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
+                dbuf_count += run_t;
+                obase = dbuf_count;
+                run_t = 0;
+              }
+            }
+            if (next_sym == PIPE_EOB) stopc |= 1u;
+            else if (dbuf_count >= dbuf_size) stopc = 2;
+            else if (!stopc) {
+              const uint32_t k = next_sym - 1;
+              const uint32_t v = (__builtin_amdgcn_readlane(L, k >> 2) >> (8u * (k & 3u))) & 0xFFu;
+              const uint32_t vv = v << 24;
+              const uint32_t up = __builtin_amdgcn_update_dpp(vv, L, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+              const uint32_t shifted = __builtin_amdgcn_alignbit(L, up, 24);
+              int nb = (int)k - lane4m1;
+              nb = nb < 0 ? 0 : nb > 4 ? 4 : nb;
+              const uint32_t m = (uint32_t)((1ull << (8 * nb)) - 1ull);
+              L = (shifted & m) | (L & ~m);
+              const uint32_t slot = dbuf_count - obase;
+              outb = (uint32_t)lane == slot ? v : outb;
+              dbuf_count++;
+              if (slot == 63) { tt[obase + lane] = (uint8_t)outb; obase = dbuf_count; }
+            }
+          }
+        }
+        if (stopc & 2u) err = CJS_E_DATA_ERROR;
+        else if (stopc & 1u) done = true;
+        rd += nb_;
+        if (lane == 0) __hip_atomic_store(&P.rd, rd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (!err && done && (uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;
+      if (lane == 0 && blockIdx.x == 0) { g_dec_clk[0] = dbg_empty; g_dec_clk[1] = dbg_batches; g_dec_clk[2] = wall_clock64() - t_c0; }
+      if (lane == 0) {
+        P.cerr = err; P.count = dbuf_count;
+        if (err) __hip_atomic_fetch_or(&P.stop, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BlockOut bo;
+    int err = P.perr ? P.perr : P.cerr;
+    if (!err && P.orig >= P.count) err = CJS_E_DATA_ERROR;      // :1677
+    bo.end_bit = P.end_bit; bo.count = P.count; bo.orig = P.orig; bo.crc = P.crc; bo.err = err;
+    outs[c] = bo;
+  }
 }
 
 // ---------------------------------------------------------------- 4. inverse BWT
@@ -735,13 +952,19 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   std::vector<BlockOut> bos(ncand);
   if (ncand) {
     static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
+    static const bool v2 = getenv("CJS_DECODE_V2") != nullptr;      // the one-wave cooperative loop
     if (v1) hipLaunchKernelGGL(bz_decode_block<1>, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
-    else hipLaunchKernelGGL(bz_decode_block<2>, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
+    else if (v2) hipLaunchKernelGGL(bz_decode_block<2>, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
+    else hipLaunchKernelGGL(bz_decode_block_pipe, dim3(ncand), dim3(128), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_bo);
     if (hipMemcpyAsync(bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
     if (getenv("CJS_DEBUG")) {
       uint64_t clk[8];
       if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess)
-        fprintf(stderr, "[cjs dec] candidate 0: header+selectors+lengths %.1f us, tables %.1f us, symbol loop %.1f us\n", (clk[1] - clk[0]) / 100.0, (clk[2] - clk[1]) / 100.0, (clk[3] - clk[2]) / 100.0);
+      {
+        if (v1 || v2) fprintf(stderr, "[cjs dec] candidate 0: header+selectors+lengths %.1f us, tables %.1f us, symbol loop %.1f us\n", (clk[1] - clk[0]) / 100.0, (clk[2] - clk[1]) / 100.0, (clk[3] - clk[2]) / 100.0);
+        else fprintf(stderr, "[cjs dec] candidate 0 (two-wave pipeline): %llu symbols; producer %.1f us, %llu rounds, waited for ring space %llu times; consumer %.1f us, %llu batches, found the ring empty %llu times\n",
+                     (unsigned long long)clk[7], clk[6] / 100.0, (unsigned long long)clk[5], (unsigned long long)clk[4], clk[2] / 100.0, (unsigned long long)clk[1], (unsigned long long)clk[0]);
+      }
     }
   }
   // chain walk (Bunzip.decode :1776-1794)
