@@ -58,6 +58,8 @@ def load_library():
     L.cjs_bwtc_decompress.argtypes = [u8p, S, PP, PS, V]
     L.cjs_free.argtypes = [V]
     L.cjs_free.restype = None
+    L.cjs_trim.argtypes = []
+    L.cjs_trim.restype = None
     L.cjs_strerror.argtypes = [I]
     L.cjs_strerror.restype = ctypes.c_char_p
     L.cjs_version.restype = ctypes.c_char_p
@@ -179,3 +181,8 @@ class DeviceContext:
                                                       ctypes.byref(bits), crcs.ctypes.data, crc_cap, ctypes.byref(total),
                                                       ctypes.byref(stats) if stats is not None else None))
         return bits.value, total.value, crcs[: total.value]
+
+
+def trim():
+    """Give the workspace that cjs_bzip2_compress keeps per device between calls back to the driver."""
+    load_library().cjs_trim()

@@ -9,6 +9,8 @@
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -96,6 +98,22 @@ extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
   c->arena.destroy();
   delete c;
 }
+
+// Per-device state kept between host-buffer calls (cjs_bzip2_compress); guarded by its mutex for the whole call.
+constexpr int MAX_CACHED_DEVICES = 64;
+struct HostCache {
+  std::mutex mu;
+  cjs_ctx* ctx = nullptr;
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  size_t in_cap = 0, out_cap = 0;
+  void release() {
+    if (ctx) cjs_ctx_destroy(ctx);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    ctx = nullptr; d_in = d_out = nullptr; in_cap = out_cap = 0;
+  }
+};
+static HostCache g_host_cache[MAX_CACHED_DEVICES];
 
 // Shared body: stage 0..tables for the whole stream, then pack blocks [first, first+count).
 static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, long first, long count, bool framed,
@@ -272,26 +290,64 @@ extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_
   uint32_t nshards = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->n_devices : 0;
   if (const char* e = getenv("CJS_DEVICES")) nshards = (uint32_t)atoi(e);   // lets JS / Python callers shard without an opts struct
   if (nshards > 1 && n > 0) return compress_multi(in, n, level, nshards > 64 ? 64 : nshards, out, out_n);
-  cjs_ctx* c = nullptr;
-  CJS_TRY(cjs_ctx_create(&c, -1, n, level));
+  // The workspace (~70 B per input byte), the staging buffers and the streams are kept per device between calls
+  // (creating and freeing them costs more than compressing 100 MB); cjs_trim() or CJS_NO_CTX_CACHE=1 gives them back.
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_CACHED_DEVICES) return CJS_E_HIP;
+  static const bool no_cache = getenv("CJS_NO_CTX_CACHE") != nullptr;
+  HostCache& hc = g_host_cache[dev];
+  std::lock_guard<std::mutex> lock(hc.mu);
   const size_t out_cap = (n + n / 4 + 4096 + 3) & ~(size_t)3;
-  uint8_t *d_in = nullptr, *d_out = nullptr;
   int rc = 0;
-  if (hipMalloc((void**)&d_in, n ? n : 4) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
-  if (!rc && hipMalloc((void**)&d_out, out_cap) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
-  if (!rc && n && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = CJS_E_HIP;
+  static const bool dbg = getenv("CJS_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  if (!hc.ctx || hc.ctx->level != level || hc.ctx->max_input < n) {
+    if (hc.ctx) { cjs_ctx_destroy(hc.ctx); hc.ctx = nullptr; }
+    rc = cjs_ctx_create(&hc.ctx, -1, n, level);
+    if (rc) { hc.ctx = nullptr; return rc; }
+  }
+  if (hc.in_cap < n || !hc.d_in) {
+    if (hc.d_in) (void)hipFree(hc.d_in);
+    hc.d_in = nullptr; hc.in_cap = 0;
+    if (hipMalloc((void**)&hc.d_in, n ? n : 4) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY; else hc.in_cap = n ? n : 4;
+  }
+  if (!rc && (hc.out_cap < out_cap || !hc.d_out)) {
+    if (hc.d_out) (void)hipFree(hc.d_out);
+    hc.d_out = nullptr; hc.out_cap = 0;
+    if (hipMalloc((void**)&hc.d_out, out_cap) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY; else hc.out_cap = out_cap;
+  }
+  cjs_ctx* c = hc.ctx;
+  const auto t1 = now();
+  if (!rc && n && hipMemcpyAsync(hc.d_in, in, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = CJS_E_HIP;
+  if (dbg && !rc) (void)hipStreamSynchronize(c->stream);
+  const auto t2 = now();
   size_t len = 0;
   cjs_stats* st = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->stats : nullptr;
-  if (!rc) rc = cjs_bzip2_compress_device(c, d_in, n, level, d_out, out_cap, &len, st);
+  if (!rc) rc = cjs_bzip2_compress_device(c, hc.d_in, n, level, hc.d_out, out_cap, &len, st);
+  const auto t3 = now();
   uint8_t* host = nullptr;
   if (!rc) { host = (uint8_t*)malloc(len ? len : 1); if (!host) rc = CJS_E_OUT_OF_MEMORY; }
-  if (!rc && hipMemcpy(host, d_out, len, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
-  if (d_in) (void)hipFree(d_in);
-  if (d_out) (void)hipFree(d_out);
-  cjs_ctx_destroy(c);
+  if (!rc && hipMemcpy(host, hc.d_out, len, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+  const auto t4 = now();
+  if (dbg) fprintf(stderr, "[cjs] host compress: workspace %.2f ms, H2D %.2f ms, pipeline %.2f ms, malloc + D2H %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
+  if (rc || no_cache) hc.release();           // after an error the cached state is not trusted
   if (rc) { free(host); return rc; }
   *out = host; *out_n = len;
   return 0;
+}
+
+extern "C" void cjs_trim(void) {
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  for (int d = 0; d < MAX_CACHED_DEVICES; d++) {
+    HostCache& hc = g_host_cache[d];
+    std::lock_guard<std::mutex> lock(hc.mu);
+    if (!hc.ctx && !hc.d_in && !hc.d_out) continue;
+    if (hipSetDevice(d) == hipSuccess) hc.release();
+  }
+  if (have) (void)hipSetDevice(cur);
 }
 
 // ------------------------------------------------------------------ stage-level entry points (tests)

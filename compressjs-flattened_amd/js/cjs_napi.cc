@@ -25,6 +25,7 @@ struct Api {
   const char* (*strerror_)(int) = nullptr;
   int (*device_count)(void) = nullptr;
   const char* (*version)(void) = nullptr;
+  void (*trim)(void) = nullptr;
   std::string error;
 } api;
 
@@ -45,7 +46,7 @@ bool load_api() {
   SYM(bzip2_compress, "cjs_bzip2_compress") SYM(bzip2_decompress, "cjs_bzip2_decompress")
   SYM(bwtc_compress, "cjs_bwtc_compress") SYM(bwtc_decompress, "cjs_bwtc_decompress")
   SYM(bzip2_table, "cjs_bzip2_table") SYM(bzip2_decompress_block, "cjs_bzip2_decompress_block")
-  SYM(free_, "cjs_free") SYM(strerror_, "cjs_strerror") SYM(device_count, "cjs_device_count") SYM(version, "cjs_version")
+  SYM(free_, "cjs_free") SYM(strerror_, "cjs_strerror") SYM(device_count, "cjs_device_count") SYM(version, "cjs_version") SYM(trim, "cjs_trim")
 #undef SYM
   return true;
 }
@@ -158,6 +159,12 @@ napi_value version(napi_env env, napi_callback_info) {
   napi_value v; napi_create_string_utf8(env, api.version(), NAPI_AUTO_LENGTH, &v); return v;
 }
 
+napi_value trim(napi_env env, napi_callback_info) {          // releases the workspace the library keeps between compress calls
+  if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
+  api.trim();
+  napi_value v; napi_get_undefined(env, &v); return v;
+}
+
 napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
     {"bzip2Compress", nullptr, call_stream<0>, nullptr, nullptr, nullptr, napi_default, nullptr},
@@ -168,6 +175,7 @@ napi_value init(napi_env env, napi_value exports) {
     {"bzip2DecompressBlock", nullptr, bzip2_block, nullptr, nullptr, nullptr, napi_default, nullptr},
     {"deviceCount", nullptr, device_count, nullptr, nullptr, nullptr, napi_default, nullptr},
     {"version", nullptr, version, nullptr, nullptr, nullptr, napi_default, nullptr},
+    {"trim", nullptr, trim, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -72,6 +72,9 @@ int cjs_bwtc_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_
 long cjs_bzip2_table(const uint8_t *in, size_t n, int multistream, uint64_t *bitpos, uint32_t *size, long cap, const cjs_opts *opts);
 int cjs_bzip2_decompress_block(const uint8_t *in, size_t n, uint64_t bitpos, uint8_t **out, size_t *out_n, const cjs_opts *opts);
 void cjs_free(void *p);
+/* cjs_bzip2_compress keeps its per-device workspace between calls; cjs_trim() returns it to the driver
+ * (environment CJS_NO_CTX_CACHE=1: never keep it). */
+void cjs_trim(void);
 const char *cjs_strerror(int code);
 int cjs_device_count(void);
 const char *cjs_version(void);

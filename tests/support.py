@@ -221,6 +221,8 @@ class HipLib(_StreamLib):
         L.cjs_strerror.restype = ctypes.c_char_p
         L.cjs_version.restype = ctypes.c_char_p
         L.cjs_free.restype = None
+        L.cjs_trim.argtypes = []
+        L.cjs_trim.restype = None
         if hasattr(L, "cjs_bzip2_table"):
             L.cjs_bzip2_table.restype = ctypes.c_long
 

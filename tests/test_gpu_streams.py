@@ -201,6 +201,21 @@ def test_multi_device_host_path_equals_single(hip, oracle, monkeypatch):
     assert rc == 0 and np.array_equal(out, want)
 
 
+def test_cached_workspace_across_calls(hip, oracle):
+    # cjs_bzip2_compress keeps its per-device workspace: growing / shrinking inputs, a level change, cjs_trim in between
+    seq = [(300000, 9, 21), (2500000, 9, 22), (1000, 9, 23), (700000, 1, 24), (0, 1, 25), (1200000, 5, 26)]
+    for i, (n, level, seed) in enumerate(seq):
+        data = recipes.textgen(n, seed) if n else np.empty(0, dtype=np.uint8)
+        rc, want = oracle.bzip2_compress(data, level)
+        rc2, out = hip.bzip2_compress(data, level)
+        assert rc == 0 and rc2 == 0 and np.array_equal(out, want), "call %d (n=%d level=%d)" % (i, n, level)
+        if i == 2:
+            hip.L.cjs_trim()
+    hip.L.cjs_trim()
+    rc2, out = hip.bzip2_compress(recipes.textgen(50000, 27), 9)
+    assert rc2 == 0 and np.array_equal(out, oracle.bzip2_compress(recipes.textgen(50000, 27), 9)[1])
+
+
 def test_onesweep_variant_is_bit_exact(hip, oracle, monkeypatch):
     # the opt-in look-back radix passes must give the same stream
     data = recipes.textgen(2500000, 4)
