@@ -21,6 +21,7 @@
 #include "prims.hpp"
 #include "rle1.h"
 #include <algorithm>
+#include <chrono>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -919,6 +920,10 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   if (level < 1 || level > 9) return CJS_E_NOT_BZIP_DATA;
   uint32_t dbuf_size = 100000u * (uint32_t)level;
 
+  static const bool dbg_t = getenv("CJS_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto msd = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto T0 = now();
   hipStream_t s = nullptr;
   uint8_t* d_in = nullptr; Cand* d_cand = nullptr; uint32_t* d_count = nullptr;
   const uint32_t cand_cap = (uint32_t)(n / 64 + 1024);
@@ -950,6 +955,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   if (!rc) rc = dmalloc((void**)&d_bo, sizeof(BlockOut) * (ncand ? ncand : 1));
   if (rc) { cleanup(); return rc; }
   std::vector<BlockOut> bos(ncand);
+  const auto T1 = now();
   if (ncand) {
     static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
     static const bool v2 = getenv("CJS_DECODE_V2") != nullptr;      // the one-wave cooperative loop
@@ -967,6 +973,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
       }
     }
   }
+  const auto T2 = now();
   // chain walk (Bunzip.decode :1776-1794)
   auto find = [&](uint64_t bit) -> long {
     size_t lo = 0, hi = cands.size();
@@ -1084,7 +1091,9 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block %u: Bad block CRC (got %08x expected %08x) out_len %u\n", k, crcs[k], chain[k].crc, chain[k].out_len);
     rc = CJS_E_DATA_ERROR; break;
   }
+  const auto T3 = now();
   cleanup();
+  if (dbg_t) fprintf(stderr, "[cjs dec] host phases: H2D + magic scan + candidate buffers %.2f ms, block decode %.2f ms, chain + inverse BWT + RLE1 + CRC + D2H %.2f ms, free %.2f ms\n", msd(T0, T1), msd(T1, T2), msd(T2, T3), msd(T3, now()));
   if (rc) { free(host); return rc; }
   if (tab_n) {
     *tab_n = (long)nb;
