@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ ke
 }
 
 // single workgroup: exclusive sums of [0],[1]; exclusive prefix-max of [2]; totals -> counters[0..1]
-__global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ tile_cnt, uint32_t T, uint32_t* __restrict__ counters) {
+__global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ tile_cnt, uint32_t T, uint32_t* __restrict__ counters,
+                                                      uint32_t* __restrict__ host_mirror /* pinned host memory, read after the stream sync */) {
   __shared__ uint32_t sm[16];
   __shared__ uint32_t mx[1024];
   uint32_t c0 = 0, c1 = 0, cm = 0;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ ti
     }
     c0 += t0; c1 += t1; cm = chunk_max > cm ? chunk_max : cm;
   }
-  if (threadIdx.x == 0) { counters[0] = c0; counters[1] = c1; }
+  if (threadIdx.x == 0) { counters[0] = c0; counters[1] = c1; host_mirror[0] = c0; host_mirror[1] = c1; }
 }
 
 // regroup: new ranks -> R (scattered 4-byte stores), singletons -> SA, survivors compacted into the next
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
   }
 }
 // single workgroup: exclusive scan of n counters in place, total -> *total
-__global__ __launch_bounds__(1024) void scan_u32_single(uint32_t* __restrict__ arr, uint32_t n, uint32_t* __restrict__ total) {
+__global__ __launch_bounds__(1024) void scan_u32_single(uint32_t* __restrict__ arr, uint32_t n, uint32_t* __restrict__ total, uint32_t* __restrict__ host_total) {
   __shared__ uint32_t sm[16];
   uint32_t carry = 0;
   for (uint32_t base = 0; base < n; base += 1024) {
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(1024) void scan_u32_single(uint32_t* __restrict__ a
     if (i < n) arr[i] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0) *total = carry;
+  if (threadIdx.x == 0) { *total = carry; *host_total = carry; }
 }
 __global__ __launch_bounds__(256) void bwt_defer_count(uint32_t A, const uint8_t* __restrict__ dflag, uint32_t* __restrict__ tcount) {
   __shared__ uint32_t sm[4];
@@ -914,8 +915,7 @@ static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int
   CJS_HIP_TRY(hipMemsetAsync(dflag, 1, A, s));
   launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag);
   hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, tcount);
-  hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2);
-  CJS_HIP_TRY(hipMemcpyAsync(w.h_counters + 2, w.counters + 2, 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2, w.h_counters + 2);      // the kernel writes the pinned mirror itself
   CJS_HIP_TRY(hipStreamSynchronize(s));
   const uint32_t D = w.h_counters[2];
   if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt]   tile sort: %u of %u suffixes in groups > %u\n", D, A, TS_MAXGRP);
@@ -970,12 +970,14 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T);
-    hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters);
+    hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
     if (rounds == 0) hipLaunchKernelGGL(bwt_apply<true>, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                                         w.val[1 - c], w.pos[1 - pc], w.gord);
     else hipLaunchKernelGGL(bwt_apply<false>, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                             w.val[1 - c], w.pos[1 - pc], w.gord);
-    CJS_HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters, 40, hipMemcpyDeviceToHost, s));
+    static const bool onesweep = getenv("CJS_ONESWEEP") != nullptr;
+    if (onesweep) CJS_HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters, 40, hipMemcpyDeviceToHost, s));      // (its look-back error flag; the round counters arrive through the pinned mirror)
+    else w.h_counters[9] = 0;
     CJS_HIP_TRY(hipStreamSynchronize(s));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
