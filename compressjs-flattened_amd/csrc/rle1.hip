@@ -317,7 +317,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
                                                  RleBlock* __restrict__ blocks, uint32_t max_blocks, uint32_t* __restrict__ nblocks_out) {
   __shared__ uint32_t smem[1024 + 16];
   __shared__ unsigned long long sh64[2];
-  __shared__ unsigned long long spec_e[1024];
+  __shared__ unsigned long long spec_e[NSPEC];
   __shared__ uint32_t spec_first_bad;
   uint64_t s = 0;
   uint32_t k = 0;
