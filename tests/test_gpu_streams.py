@@ -201,6 +201,47 @@ def test_multi_device_host_path_equals_single(hip, oracle, monkeypatch):
     assert rc == 0 and np.array_equal(out, want)
 
 
+def _mixed_input(seed):
+    """text, binary noise, low-entropy noise, long runs and periodic stretches in one stream (sizes from the seed)"""
+    rng = np.random.RandomState(seed)
+    parts = []
+    for _ in range(int(rng.randint(3, 9))):
+        kind = int(rng.randint(0, 6))
+        n = int(rng.randint(1, 400000))
+        if kind == 0:
+            parts.append(recipes.textgen(n, int(rng.randint(1, 1 << 30))))
+        elif kind == 1:
+            parts.append(rng.randint(0, 256, n).astype(np.uint8))
+        elif kind == 2:
+            parts.append((rng.randint(0, 4, n) + 97).astype(np.uint8))
+        elif kind == 3:
+            parts.append(np.full(int(rng.randint(1, 3000)), int(rng.randint(0, 256)), dtype=np.uint8))
+        elif kind == 4:
+            unit = rng.randint(0, 256, int(rng.randint(1, 40))).astype(np.uint8)
+            parts.append(np.tile(unit, n // len(unit) + 1)[:n])
+        else:
+            page = recipes.textgen(int(rng.randint(50, 3000)), int(rng.randint(1, 1 << 30)))
+            parts.append(np.tile(page, int(rng.randint(2, 60))))
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_mixed_content_vs_oracle(hip, oracle, seed):
+    # random mixtures, random level: Bzip2 and BWTC streams equal the oracle's, and both decoders give the input back
+    data = _mixed_input(1000 + seed)
+    level = 1 + (seed * 5) % 9
+    rc, want = oracle.bzip2_compress(data, level)
+    rc2, got = hip.bzip2_compress(data, level)
+    assert rc == 0 and rc2 == 0 and np.array_equal(got, want), "bzip2 level %d, %d bytes" % (level, data.size)
+    rc3, back = hip.bzip2_decompress(got)
+    assert rc3 == 0 and np.array_equal(back, data)
+    rc, want = oracle.bwtc_compress(data, level)
+    rc2, got = hip.bwtc_compress(data, level)
+    assert rc == 0 and rc2 == 0 and np.array_equal(got, want), "bwtc level %d, %d bytes" % (level, data.size)
+    rc3, back = hip.bwtc_decompress(got)
+    assert rc3 == 0 and np.array_equal(back, data)
+
+
 def test_cached_workspace_across_calls(hip, oracle):
     # cjs_bzip2_compress keeps its per-device workspace: growing / shrinking inputs, a level change, cjs_trim in between
     seq = [(300000, 9, 21), (2500000, 9, 22), (1000, 9, 23), (700000, 1, 24), (0, 1, 25), (1200000, 5, 26)]
