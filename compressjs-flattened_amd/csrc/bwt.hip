@@ -628,9 +628,11 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
                   : (((uint64_t)x << 52) | (0xFFFFFull << 32));
   }
   __syncthreads();            // gk (aliasing sk) is dead from here
-  // groups of <= TS_TINY members: every member counts the smaller members of its group
+  // groups of <= TS_TINY members: every member counts the smaller members of its group.  Inside a group only the
+  // 20-bit rank key matters (equal keys stay one group, any order): 32-bit words (key << 12 | slot) are compared
+  uint32_t* sk32 = reinterpret_cast<uint32_t*>(sk);
 #pragma unroll
-  for (int it = 0; it < 16; it++) sk[(uint32_t)it * 256u + tid] = r[it];
+  for (int it = 0; it < 16; it++) { const uint32_t x = (uint32_t)it * 256u + tid; sk32[x] = ((uint32_t)(r[it] >> 32) << 12) | x; }
   any_medium = __syncthreads_or(any_medium);
 #pragma unroll
   for (int it = 0; it < 16; it++) {
@@ -639,8 +641,9 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     const uint32_t gmax = wave_max(g);
     if (gmax == 0) continue;
     const uint64_t mine = r[it];
+    const uint32_t mine32 = ((uint32_t)(mine >> 32) << 12) | ((uint32_t)it * 256u + tid);
     uint32_t rank = 0;
-    for (uint32_t d = 0; d < gmax; d++) rank += (d < g && sk[hx + d] < mine) ? 1u : 0u;
+    for (uint32_t d = 0; d < gmax; d++) rank += (d < g && sk32[hx + d] < mine32) ? 1u : 0u;
     if (own) {
       key[wb + hx + rank] = ((uint64_t)go[it] << 20) | ((mine >> 32) & 0xFFFFFull);
       val[wb + hx + rank] = (uint32_t)mine;
