@@ -17,6 +17,7 @@ struct Rle1Work {
   uint32_t cap = 0, max_blocks = 0, max_segs = 0, range_blocks = 0;
   uint32_t* h_n = nullptr;       // pinned host scalar
   uint64_t *fb = nullptr, *lb = nullptr, *gt = nullptr;
+  unsigned long long* agg = nullptr;     // chunk aggregates of the three-phase tile scans
   uint16_t* subpre = nullptr;    // [tiles][16] emitted bytes of the tile before each 256-byte subtile
   uint8_t* dmod = nullptr;       // [tiles][16] chunk phase of each subtile's first byte
   RleBlock* blocks = nullptr;

@@ -103,44 +103,7 @@ __global__ __launch_bounds__(256) void rle_tile_summary(const uint8_t* __restric
 }
 
 // ---- P2: run_start_in[t] = start of the run containing the tile's first byte (from earlier tiles);
-//          next_bnd[t] = first boundary in later tiles (N if none).  One workgroup.
-__global__ __launch_bounds__(1024) void rle_scan_boundaries(uint64_t* __restrict__ fb, uint64_t* __restrict__ lb, uint32_t Tn, uint64_t N) {
-  __shared__ unsigned long long sm[16];
-  __shared__ unsigned long long arr[1024];
-  unsigned long long carry = 0;
-  for (uint32_t base = 0; base < Tn; base += 1024) {          // exclusive prefix max of lb (pos+1)
-    const uint32_t i = base + threadIdx.x;
-    const unsigned long long v = i < Tn ? lb[i] : 0ull;
-    const unsigned long long im = block_incl_max<1024>(v, sm);
-    arr[threadIdx.x] = im;
-    __syncthreads();
-    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
-    const unsigned long long cmx = arr[1023];
-    __syncthreads();
-    if (i < Tn) { const unsigned long long e = prev > carry ? prev : carry; lb[i] = e ? e - 1 : 0ull; }   // run start position
-    carry = cmx > carry ? cmx : carry;
-  }
-  // exclusive suffix min of fb (pos+1, 0 = none) -> position or N
-  unsigned long long scarry = 0;   // stored as (MAX - (pos+1)) + 1 style: use max-scan on inverted values, 0 = none
-  const uint32_t chunks = (Tn + 1023) / 1024;
-  for (uint32_t cidx = 0; cidx < chunks; cidx++) {
-    const uint32_t base = (chunks - 1 - cidx) * 1024;
-    const uint32_t i = base + (1023 - threadIdx.x);            // reversed order inside the chunk
-    const unsigned long long f = i < Tn ? fb[i] : 0ull;
-    const unsigned long long v = f ? (NONE64 - f) : 0ull;      // larger = smaller position
-    const unsigned long long im = block_incl_max<1024>(v, sm);
-    arr[threadIdx.x] = im;
-    __syncthreads();
-    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
-    const unsigned long long cmx = arr[1023];
-    __syncthreads();
-    if (i < Tn) {
-      const unsigned long long e = prev > scarry ? prev : scarry;
-      fb[i] = e ? (NONE64 - e) - 1 : N;                        // position of the next boundary after this tile
-    }
-    scarry = cmx > scarry ? cmx : scarry;
-  }
-}
+//          next_bnd[t] = first boundary in later tiles (N if none): rle_scanb_* below (three-phase scans)
 
 // ---- P3: per-tile emitted byte count under the global chunking, plus two small tables per 256-byte subtile
 //          (used by the speculative boundary search): subpre = emitted bytes of the tile before the subtile,
@@ -170,17 +133,101 @@ __global__ __launch_bounds__(256) void rle_tile_count(const uint8_t* __restrict_
 }
 
 // ---- P4: exclusive prefix sum (u64) over tiles, one workgroup; gt[Tn] = total
-__global__ __launch_bounds__(1024) void rle_scan_counts(uint64_t* __restrict__ gt, uint32_t Tn) {
+// ---- the tile scans (P2, and the exclusive prefix of the per-tile emitted counts) as three-phase scans over chunks of
+//      1024 tiles (reduce -> scan of the chunk aggregates -> apply), so that their time does not grow with the stream (a multi-GPU job replicates this pass on every rank).
+//      agg: [0..nch) chunk max of lb, [nch..2nch) chunk max of the inverted fb, [2nch..3nch) chunk sum of gt
+constexpr uint32_t SC = 1024;
+__global__ __launch_bounds__(1024) void rle_scanb_reduce(const uint64_t* __restrict__ fb, const uint64_t* __restrict__ lb, uint32_t Tn,
+                                                         unsigned long long* __restrict__ agg, uint32_t nch) {
+  __shared__ unsigned long long sm[16];
+  const uint32_t i = blockIdx.x * SC + threadIdx.x;
+  const unsigned long long l = i < Tn ? lb[i] : 0ull, f = i < Tn ? fb[i] : 0ull;
+  const unsigned long long ml = block_incl_max<1024>(l, sm);
+  const unsigned long long mf = block_incl_max<1024>(f ? (NONE64 - f) : 0ull, sm);
+  if (threadIdx.x == 1023) { agg[blockIdx.x] = ml; agg[nch + blockIdx.x] = mf; }
+}
+// single workgroup: exclusive prefix max of agg[0..nch), exclusive SUFFIX max of agg[nch..2nch)
+__global__ __launch_bounds__(1024) void rle_scanb_mid(unsigned long long* __restrict__ agg, uint32_t nch) {
+  __shared__ unsigned long long sm[16];
+  __shared__ unsigned long long arr[1024];
+  unsigned long long carry = 0;
+  for (uint32_t base = 0; base < nch; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long v = i < nch ? agg[i] : 0ull;
+    const unsigned long long im = block_incl_max<1024>(v, sm);
+    arr[threadIdx.x] = im;
+    __syncthreads();
+    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull, cmx = arr[1023];
+    __syncthreads();
+    if (i < nch) agg[i] = prev > carry ? prev : carry;
+    carry = cmx > carry ? cmx : carry;
+  }
+  unsigned long long scarry = 0;
+  const uint32_t rounds = (nch + 1023) / 1024;
+  for (uint32_t r = 0; r < rounds; r++) {
+    const uint32_t base = (rounds - 1 - r) * 1024;
+    const uint32_t i = base + (1023 - threadIdx.x);
+    const unsigned long long v = i < nch ? agg[nch + i] : 0ull;
+    const unsigned long long im = block_incl_max<1024>(v, sm);
+    arr[threadIdx.x] = im;
+    __syncthreads();
+    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull, cmx = arr[1023];
+    __syncthreads();
+    if (i < nch) agg[nch + i] = prev > scarry ? prev : scarry;
+    scarry = cmx > scarry ? cmx : scarry;
+  }
+}
+__global__ __launch_bounds__(1024) void rle_scanb_apply(uint64_t* __restrict__ fb, uint64_t* __restrict__ lb, uint32_t Tn, uint64_t N,
+                                                        const unsigned long long* __restrict__ agg, uint32_t nch) {
+  __shared__ unsigned long long sm[16];
+  __shared__ unsigned long long arr[1024];
+  {                                                              // run start of each tile's first byte: exclusive prefix max of lb
+    const uint32_t i = blockIdx.x * SC + threadIdx.x;
+    const unsigned long long carry = agg[blockIdx.x];
+    const unsigned long long v = i < Tn ? lb[i] : 0ull;
+    const unsigned long long im = block_incl_max<1024>(v, sm);
+    arr[threadIdx.x] = im;
+    __syncthreads();
+    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
+    __syncthreads();
+    if (i < Tn) { const unsigned long long e = prev > carry ? prev : carry; lb[i] = e ? e - 1 : 0ull; }
+  }
+  {                                                              // next boundary after each tile: exclusive suffix min of fb
+    const uint32_t i = blockIdx.x * SC + (1023 - threadIdx.x);
+    const unsigned long long scarry = agg[nch + blockIdx.x];
+    const unsigned long long f = i < Tn ? fb[i] : 0ull;
+    const unsigned long long im = block_incl_max<1024>(f ? (NONE64 - f) : 0ull, sm);
+    arr[threadIdx.x] = im;
+    __syncthreads();
+    const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
+    __syncthreads();
+    if (i < Tn) { const unsigned long long e = prev > scarry ? prev : scarry; fb[i] = e ? (NONE64 - e) - 1 : N; }
+  }
+}
+__global__ __launch_bounds__(1024) void rle_scanc_reduce(const uint64_t* __restrict__ gt, uint32_t Tn, unsigned long long* __restrict__ agg, uint32_t nch) {
+  __shared__ unsigned long long sm[16];
+  const uint32_t i = blockIdx.x * SC + threadIdx.x;
+  const unsigned long long t = block_sum<1024>((unsigned long long)(i < Tn ? gt[i] : 0ull), sm);
+  if (threadIdx.x == 0) agg[2 * nch + blockIdx.x] = t;
+}
+__global__ __launch_bounds__(1024) void rle_scanc_mid(unsigned long long* __restrict__ agg, uint32_t nch, uint64_t* __restrict__ gt, uint32_t Tn) {
   __shared__ unsigned long long sm[16];
   unsigned long long carry = 0;
-  for (uint32_t base = 0; base < Tn; base += 1024) {
+  for (uint32_t base = 0; base < nch; base += 1024) {
     const uint32_t i = base + threadIdx.x;
-    unsigned long long v = i < Tn ? gt[i] : 0ull, tot;
+    unsigned long long v = i < nch ? agg[2 * nch + i] : 0ull, tot;
     const unsigned long long ex = block_excl_sum<1024>(v, sm, tot);
-    if (i < Tn) gt[i] = carry + ex;
+    if (i < nch) agg[2 * nch + i] = carry + ex;
     carry += tot;
   }
   if (threadIdx.x == 0) gt[Tn] = carry;
+}
+__global__ __launch_bounds__(1024) void rle_scanc_apply(uint64_t* __restrict__ gt, uint32_t Tn, const unsigned long long* __restrict__ agg, uint32_t nch) {
+  __shared__ unsigned long long sm[16];
+  const uint32_t i = blockIdx.x * SC + threadIdx.x;
+  unsigned long long v = i < Tn ? gt[i] : 0ull, tot;
+  const unsigned long long ex = block_excl_sum<1024>(v, sm, tot);
+  if (i < Tn) gt[i] = agg[2 * nch + blockIdx.x] + ex;
 }
 
 // in-tile helper for the walk (1024 threads x 4 positions): inclusive prefix of c at each position.
@@ -670,7 +717,7 @@ size_t Rle1Work::bytes_needed(size_t max_in, uint32_t cap, size_t range_blocks) 
   const size_t segs = max_segs_for(cap);
   size_t b = 0;
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
-  add(Tn * 8); add(Tn * 8); add((Tn + 1) * 8); add(Tn * 16 * 2); add(Tn * 16);
+  add(Tn * 8); add(Tn * 8); add((Tn + 1) * 8); add(Tn * 16 * 2); add(Tn * 16); add(3 * (Tn / 1024 + 2) * 8);
   add(maxb * sizeof(RleBlock)); add(maxb * 4); add(maxb * 4); add(64);
   add((range_blocks ? range_blocks : maxb) * segs * 4);
   return b + 4096;
@@ -681,6 +728,7 @@ int Rle1Work::carve(Arena& a, size_t max_in_, uint32_t cap_, size_t range_blocks
   max_blocks = (uint32_t)max_blocks_for(max_in, cap);
   max_segs = (uint32_t)max_segs_for(cap);
   fb = a.take<uint64_t>(Tn); lb = a.take<uint64_t>(Tn); gt = a.take<uint64_t>(Tn + 1);
+  agg = a.take<unsigned long long>(3 * (Tn / 1024 + 2));
   subpre = a.take<uint16_t>(Tn * 16); dmod = a.take<uint8_t>(Tn * 16);
   blocks = a.take<RleBlock>(max_blocks); block_len = a.take<uint32_t>(max_blocks); block_crc = a.take<uint32_t>(max_blocks);
   nblocks = a.take<uint32_t>(16);
@@ -706,9 +754,14 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32
   if (N == 0) { *nblocks_host = 0; CJS_HIP_TRY(hipMemsetAsync(w.nblocks, 0, 4, s)); return 0; }
   const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
   hipLaunchKernelGGL(rle_tile_summary, dim3(Tn), dim3(256), 0, s, d_in, N, w.fb, w.lb);
-  hipLaunchKernelGGL(rle_scan_boundaries, dim3(1), dim3(1024), 0, s, w.fb, w.lb, Tn, N);
+  const uint32_t nch = (Tn + SC - 1) / SC;
+  hipLaunchKernelGGL(rle_scanb_reduce, dim3(nch), dim3(1024), 0, s, w.fb, w.lb, Tn, w.agg, nch);
+  hipLaunchKernelGGL(rle_scanb_mid, dim3(1), dim3(1024), 0, s, w.agg, nch);
+  hipLaunchKernelGGL(rle_scanb_apply, dim3(nch), dim3(1024), 0, s, w.fb, w.lb, Tn, N, w.agg, nch);
   hipLaunchKernelGGL(rle_tile_count, dim3(Tn), dim3(256), 0, s, d_in, N, w.lb, w.gt, w.subpre, w.dmod);
-  hipLaunchKernelGGL(rle_scan_counts, dim3(1), dim3(1024), 0, s, w.gt, Tn);
+  hipLaunchKernelGGL(rle_scanc_reduce, dim3(nch), dim3(1024), 0, s, w.gt, Tn, w.agg, nch);
+  hipLaunchKernelGGL(rle_scanc_mid, dim3(1), dim3(1024), 0, s, w.agg, nch, w.gt, Tn);
+  hipLaunchKernelGGL(rle_scanc_apply, dim3(nch), dim3(1024), 0, s, w.gt, Tn, w.agg, nch);
   hipLaunchKernelGGL(rle_walk, dim3(1), dim3(1024), 0, s, d_in, N, w.cap, Tn, w.lb, w.fb, w.gt, w.subpre, w.dmod, w.blocks, w.max_blocks, w.nblocks);
   hipLaunchKernelGGL(rle_block_lens, dim3((w.max_blocks + 255) / 256), dim3(256), 0, s, w.blocks, w.nblocks, w.block_len);
   CJS_HIP_TRY(hipGetLastError());
