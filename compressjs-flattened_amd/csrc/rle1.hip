@@ -275,7 +275,7 @@ __device__ void walk_tile_eval(const uint8_t* __restrict__ in, uint64_t N, uint6
 // chunking), the next boundaries are where G reaches G(s0) + j*cap.  Group j (32 lanes) looks boundary j up
 // (search on G_tile, then the subtile table, then the <= 256 bytes of the subtile).  A boundary is "clean" when G hits
 // the target exactly and the next block again starts on a run boundary; blocks up to the first unclean boundary
-// are exact, the unclean one is resolved by one serial step of the general rule, and speculation resumes.
+// are exact; the next round then starts inside a run (see rle_walk).
 struct SpecOut { uint64_t e; uint32_t clean; uint32_t eof; uint32_t len_last; };
 // The search for ONE target is done by a group of 32 lanes: 32-ary search on G_tile (3 dependent loads instead of the
 // 15 of a binary search), one ballot over the 16 subtile prefixes, and the 256-byte subtile scanned 8 bytes per lane with two
@@ -372,13 +372,63 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
   uint64_t dbg_n[2] = {0, 0}, dbg_t[2] = {0, 0}, dbg_p[3] = {0, 0, 0};
   while (s < N && k < max_blocks && !done) {
     const uint64_t t_in = wall_clock64();
-    // ---- speculative rounds: only from a run boundary
+    // A round starts at s.  If s is a run boundary, fresh chunking == global chunking from s on and boundary j is where
+    // G reaches G(s) + (j+1)*cap.  If s lies inside a run, only that run is chunked differently: with r_end its end and
+    // base = bytes it emits under fresh chunking, the same holds with G(s) replaced by G(r_end) - base - unless the
+    // block fills up inside the run or the run reaches the end of the input (closed forms below).
+    uint64_t G0, r_end0 = s, Gr0; uint32_t base0 = 0;
     if (s == 0 || in[s] != in[s - 1]) {
       // G(s): tile prefix + in-tile prefix (one cooperative tile evaluation)
       const uint32_t t0 = (uint32_t)(s / RT);
       uint64_t fp; uint32_t below;
       walk_tile_eval(in, N, (uint64_t)t0 * RT, run_start_in[t0], 0, NONE64, s, smem, sh64, fp, below);
-      const uint64_t G0 = gt[t0] + below;
+      G0 = gt[t0] + below; Gr0 = G0;
+    } else {
+      // end of the run containing s
+      const uint32_t ts = (uint32_t)(s / RT);
+      const uint64_t tile_end = ((uint64_t)(ts + 1) * RT < N) ? (uint64_t)(ts + 1) * RT : N;
+      if (threadIdx.x == 0) sh64[0] = NONE64;
+      __syncthreads();
+      {
+        unsigned long long mine = NONE64;
+        for (int j = 0; j < 4; j++) {
+          const uint64_t p = (uint64_t)ts * RT + (uint64_t)threadIdx.x * 4 + j;
+          if (p > s && p < tile_end && mine == NONE64 && in[p] != in[p - 1]) mine = p;
+        }
+        if (mine != NONE64) atomicMin(&sh64[0], mine);
+      }
+      __syncthreads();
+      uint64_t r_end = sh64[0];
+      __syncthreads();
+      if (r_end == NONE64) r_end = next_bnd[ts];
+      const uint64_t Lp = r_end - s;
+      const uint64_t q = Lp / 255; const uint32_t rr = (uint32_t)(Lp % 255);
+      const uint64_t g64 = 5 * q + (rr < 4 ? rr : 5u);
+      if (g64 >= cap || r_end >= N) {
+        uint64_t e; uint32_t len, base;
+        if (g64 >= cap) {                       // the block fills up inside this run
+          const uint32_t qq = cap / 5, rem = cap % 5;
+          const uint64_t m = rem == 0 ? (uint64_t)255 * (qq - 1) + 4 : (uint64_t)255 * qq + rem;
+          e = s + m; len = cap; base = cap;
+        } else { base = (uint32_t)g64; e = N; len = base; }     // the run is the tail of the input
+        if (threadIdx.x == 0) {
+          RleBlock bd; bd.s = s; bd.e = e; bd.r_end = r_end; bd.Gr = 0; bd.len = len; bd.base = base;
+          blocks[k] = bd;
+        }
+        k++;
+        s = e;
+        dbg_n[1]++; dbg_t[1] += wall_clock64() - t_in;
+        if (len < cap) break;
+        continue;
+      }
+      base0 = (uint32_t)g64; r_end0 = r_end;
+      const uint32_t tr = (uint32_t)(r_end / RT);
+      uint64_t fp; uint32_t below;
+      walk_tile_eval(in, N, (uint64_t)tr * RT, run_start_in[tr], 0, NONE64, r_end, smem, sh64, fp, below);
+      Gr0 = gt[tr] + below;
+      G0 = Gr0 - base0;                         // >= one block's worth of emitted bytes: s > 0 here
+    }
+    {
       const uint64_t t_a = wall_clock64(); dbg_p[0] += t_a - t_in;
       const uint32_t j = threadIdx.x >> 5;               // group = speculated boundary
       if (threadIdx.x == 0) spec_first_bad = NSPEC;
@@ -395,6 +445,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
       if (lead && j <= m && k + j < max_blocks) {
         const uint64_t bs = j == 0 ? s : spec_e[j - 1];
         RleBlock bd; bd.s = bs; bd.r_end = bs; bd.base = 0; bd.Gr = G0 + (uint64_t)j * cap;
+        if (j == 0) { bd.r_end = r_end0; bd.base = base0; bd.Gr = Gr0; }
         bool emit = true;
         if (so.eof) { bd.e = N; bd.len = so.len_last; emit = so.len_last > 0 && bs < N; }
         else { bd.e = so.e; bd.len = cap; }
@@ -403,7 +454,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
       __syncthreads();
       // advance: count emitted blocks
       if (m < NSPEC) {
-        // boundary m: EOF (stream ends) or unclean (continue with the general rule from its end)
+        // boundary m: EOF (stream ends) or unclean (the next round starts inside a run)
         const unsigned long long e_m = spec_e[m];
         // was block m emitted?  eof with zero length -> not
         const uint64_t tgt_prev = G0 + (uint64_t)m * cap;
@@ -413,69 +464,7 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
       } else { k += NSPEC; s = spec_e[NSPEC - 1]; }
       __syncthreads();
       dbg_n[0]++; dbg_t[0] += wall_clock64() - t_in;
-      continue;
     }
-    // end of the run containing s
-    const uint32_t ts = (uint32_t)(s / RT);
-    const uint64_t tile_end = ((uint64_t)(ts + 1) * RT < N) ? (uint64_t)(ts + 1) * RT : N;
-    if (threadIdx.x == 0) sh64[0] = NONE64;
-    __syncthreads();
-    {
-      unsigned long long mine = NONE64;
-      for (int j = 0; j < 4; j++) {
-        const uint64_t p = (uint64_t)ts * RT + (uint64_t)threadIdx.x * 4 + j;
-        if (p > s && p < tile_end && mine == NONE64 && in[p] != in[p - 1]) mine = p;
-      }
-      if (mine != NONE64) atomicMin(&sh64[0], mine);
-    }
-    __syncthreads();
-    uint64_t r_end = sh64[0];
-    __syncthreads();
-    if (r_end == NONE64) r_end = next_bnd[ts];
-    const uint64_t Lp = r_end - s;
-    const uint64_t q = Lp / 255; const uint32_t rr = (uint32_t)(Lp % 255);
-    const uint64_t g64 = 5 * q + (rr < 4 ? rr : 5u);
-    uint64_t e; uint32_t len, base = 0; uint64_t Gr = 0;
-    if (g64 >= cap) {                       // the block fills up inside this run
-      const uint32_t qq = cap / 5, rem = cap % 5;
-      const uint64_t m = rem == 0 ? (uint64_t)255 * (qq - 1) + 4 : (uint64_t)255 * qq + rem;
-      e = s + m; len = cap; base = cap;
-    } else {
-      base = (uint32_t)g64;
-      if (r_end >= N) { e = N; len = base; }
-      else {
-        const uint32_t tr = (uint32_t)(r_end / RT);
-        uint64_t fp; uint32_t below;
-        walk_tile_eval(in, N, (uint64_t)tr * RT, run_start_in[tr], 0, NONE64, r_end, smem, sh64, fp, below);
-        Gr = gt[tr] + below;
-        const uint64_t target = (uint64_t)cap - base + Gr;
-        // last tile t* in [tr, Tn) with gt[t*] < target  (gt[tr] <= Gr < target)
-        uint32_t lo = tr, hi = Tn;
-        while (hi - lo > 1) {
-          const uint32_t span = hi - lo, step = (span + 1023) / 1024;
-          if (threadIdx.x == 0) sh64[1] = lo;
-          __syncthreads();
-          const uint64_t idx = (uint64_t)lo + (uint64_t)threadIdx.x * step;
-          if (idx < hi && gt[idx] < target) atomicMax(&sh64[1], (unsigned long long)idx);
-          __syncthreads();
-          const uint32_t nlo = (uint32_t)sh64[1];
-          __syncthreads();
-          hi = (uint64_t)nlo + step < hi ? nlo + step : hi;
-          lo = nlo;
-        }
-        walk_tile_eval(in, N, (uint64_t)lo * RT, run_start_in[lo], gt[lo], target, 0, smem, sh64, fp, below);
-        if (fp != NONE64) { e = fp + 1; len = cap; }
-        else { e = N; len = (uint32_t)(base + (gt[Tn] - Gr)); }
-      }
-    }
-    if (threadIdx.x == 0) {
-      RleBlock bd; bd.s = s; bd.e = e; bd.r_end = r_end; bd.Gr = Gr; bd.len = len; bd.base = base;
-      blocks[k] = bd;
-    }
-    k++;
-    s = e;
-    dbg_n[1]++; dbg_t[1] += wall_clock64() - t_in;
-    if (len < cap) break;
   }
   if (threadIdx.x == 0) { *nblocks_out = k; g_walk_dbg[0] = dbg_n[0]; g_walk_dbg[1] = dbg_n[1]; g_walk_dbg[2] = dbg_t[0]; g_walk_dbg[3] = dbg_t[1]; g_walk_dbg[4] = dbg_p[0]; g_walk_dbg[5] = dbg_p[1]; g_walk_dbg[6] = dbg_p[2]; }
 }
