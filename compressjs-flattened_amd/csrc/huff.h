@@ -13,7 +13,9 @@ struct HuffBufs {
   uint32_t* ngroups;  // [nb]
   uint32_t* bitlen;   // [nb] bits of the block incl. its 48-bit magic and CRC
   uint64_t* bitoff;   // [nb+1] absolute bit offset of each block in the output
-  size_t sel_stride;
+  uint32_t* databits; // [nb] bits of the block's symbol data (the last part of the block)
+  uint32_t* tileoff;  // [nb][tile_stride] bit offset of every 80-group (4000-symbol) tile inside the symbol data
+  size_t sel_stride, tile_stride;
 };
 
 struct HuffWork {

@@ -19,6 +19,7 @@ namespace cjs {
 constexpr int MAXSYM = 258;
 constexpr int MAX_BITS = 20;
 constexpr int GSZ = 50;
+constexpr int PD_GROUPS = 80;            // groups per data-packing tile (4000 symbols)
 
 // phase clock of workgroup 0 (CJS_DEBUG only): 100 MHz ticks at the marks of huff_block
 __device__ uint64_t g_huff_clk[32];
@@ -294,9 +295,18 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
 
   HB_MARK(7);
   // ---- bit accounting
+  // data bits, and the bit offset of every 80-group tile inside the data (the tiles are packed in parallel)
   uint32_t data_bits = 0;
-  for (uint32_t g = threadIdx.x; g < nsel; g += 1024) data_bits += bcost[g];
-  data_bits = block_sum<1024>(data_bits, S.sm);
+  {
+    const uint32_t ntile = (nsel + PD_GROUPS - 1) / PD_GROUPS;                     // <= 226
+    uint32_t tsum = 0;
+    if (threadIdx.x < ntile) {
+      const uint32_t g1 = (threadIdx.x + 1) * PD_GROUPS < nsel ? (threadIdx.x + 1) * PD_GROUPS : nsel;
+      for (uint32_t g = threadIdx.x * PD_GROUPS; g < g1; g++) tsum += bcost[g];
+    }
+    const uint32_t tex = block_excl_sum<1024>(tsum, S.sm, data_bits);
+    if (threadIdx.x < ntile) hb.tileoff[(size_t)blk * hb.tile_stride + threadIdx.x] = tex;
+  }
   // selector MTF positions (Bzip2:2170-2182): j = #values more recent than the previous occurrence
   uint32_t sel_bits = 0;
   {
@@ -373,6 +383,7 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
   if (threadIdx.x == 0) {
     hb.ngroups[blk] = (uint32_t)ng;
     hb.bitlen[blk] = 80u + 25u + 16u + 16u * nranges + 18u + sel_bits + tab_bits + data_bits;
+    hb.databits[blk] = data_bits;
   }
 }
 
@@ -453,8 +464,7 @@ __global__ __launch_bounds__(1024) void pack_block(HuffBufs hb, uint32_t first, 
   const uint32_t blk = blockIdx.x;                  // relative to `first`; block_crc is absolute
   const uint32_t npos = npos_all[blk], asz = asz_all[blk], ng = hb.ngroups[blk];
   const uint32_t n = asz + 2, nsel = (npos + GSZ - 1) / GSZ;
-  const uint16_t* A = Aall + (size_t)blk * a_stride;
-  const uint8_t* sel = hb.sel + (size_t)blk * hb.sel_stride;
+  (void)Aall; (void)a_stride;
   const uint8_t* selj = hb.selj + (size_t)blk * hb.sel_stride;
   for (uint32_t i = threadIdx.x; i < 6 * MAXSYM; i += 1024) { ctab[i] = hb.codes[(size_t)blk * 6 * MAXSYM + i]; ltab[i] = hb.lens[(size_t)blk * 6 * MAXSYM + i]; }
   if (threadIdx.x < 17) used16[threadIdx.x] = 0;
@@ -493,9 +503,29 @@ __global__ __launch_bounds__(1024) void pack_block(HuffBufs hb, uint32_t first, 
     if (s == 0) { v |= (uint64_t)cur << 1; nbits = 6; }      // 5-bit start length, then '0'
     return Item{v, nbits};
   }, words, sm, bit, out32);
-  // data (Bzip2:2189-2194)
-  pack_phase(npos, [&](uint32_t i) -> Item {
-    const uint32_t t = sel[i / GSZ], s = A[i];
+  // the symbol data follows: pack_data, one workgroup per 4000-symbol tile
+}
+
+// data (Bzip2:2189-2194): tile `blockIdx.x` of block `blockIdx.y`; its first bit = block start + block bits - data bits +
+// the tile's offset from huff_block.  Interior words are plain stores, the two boundary words are OR-ed.
+__global__ __launch_bounds__(1024) void pack_data(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride, const uint32_t* __restrict__ npos_all,
+                                                  uint32_t* __restrict__ out32) {
+  __shared__ uint32_t words[PK_WORDS];
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t ctab[6 * MAXSYM];
+  __shared__ uint8_t ltab[6 * MAXSYM + 4];
+  const uint32_t blk = blockIdx.y, tile = blockIdx.x;
+  const uint32_t npos = npos_all[blk], nsel = (npos + GSZ - 1) / GSZ;
+  if (tile * PD_GROUPS >= nsel) return;
+  const uint16_t* A = Aall + (size_t)blk * a_stride;
+  const uint8_t* sel = hb.sel + (size_t)blk * hb.sel_stride;
+  for (uint32_t i = threadIdx.x; i < 6 * MAXSYM; i += 1024) { ctab[i] = hb.codes[(size_t)blk * 6 * MAXSYM + i]; ltab[i] = hb.lens[(size_t)blk * 6 * MAXSYM + i]; }
+  __syncthreads();
+  uint64_t bit = hb.bitoff[blk] + hb.bitlen[blk] - hb.databits[blk] + hb.tileoff[(size_t)blk * hb.tile_stride + tile];
+  const uint32_t i0 = tile * PD_GROUPS * GSZ;
+  const uint32_t cnt = npos - i0 < (uint32_t)(PD_GROUPS * GSZ) ? npos - i0 : (uint32_t)(PD_GROUPS * GSZ);
+  pack_phase(cnt, [&](uint32_t i) -> Item {
+    const uint32_t t = sel[(i0 + i) / GSZ], s = A[i0 + i];
     return Item{ctab[t * MAXSYM + s], ltab[t * MAXSYM + s]};
   }, words, sm, bit, out32);
 }
@@ -530,6 +560,7 @@ size_t HuffWork::bytes_needed(size_t max_blocks, uint32_t stride) {
   add(max_blocks * ss); add(max_blocks * ss); add(max_blocks * ss * 2);
   add(max_blocks * 6 * MAXSYM); add(max_blocks * 6 * MAXSYM * 4);
   add(max_blocks * 4); add(max_blocks * 4); add((max_blocks + 1) * 8); add(64);
+  add(max_blocks * 4); add(max_blocks * (ss / PD_GROUPS + 2) * 4);
   return b + 4096;
 }
 int HuffWork::carve(Arena& a, size_t max_blocks_, uint32_t stride) {
@@ -540,7 +571,9 @@ int HuffWork::carve(Arena& a, size_t max_blocks_, uint32_t stride) {
   b.lens = a.take<uint8_t>(max_blocks * 6 * MAXSYM); b.codes = a.take<uint32_t>(max_blocks * 6 * MAXSYM);
   b.ngroups = a.take<uint32_t>(max_blocks); b.bitlen = a.take<uint32_t>(max_blocks); b.bitoff = a.take<uint64_t>(max_blocks + 1);
   scalars = a.take<uint64_t>(8);
-  return scalars ? 0 : CJS_E_OUT_OF_MEMORY;
+  b.tile_stride = b.sel_stride / PD_GROUPS + 2;
+  b.databits = a.take<uint32_t>(max_blocks); b.tileoff = a.take<uint32_t>(max_blocks * b.tile_stride);
+  return (scalars && b.tileoff) ? 0 : CJS_E_OUT_OF_MEMORY;
 }
 
 int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
@@ -566,7 +599,10 @@ int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first,
                   uint32_t* d_out32) {
   uint32_t* stream_crc = (uint32_t*)(w.scalars + 1);
   hipLaunchKernelGGL(huff_offsets, dim3(1), dim3(1), 0, s, w.b, d_block_crc, nb_total, first, count, start_bit, stream_crc);
-  if (count) hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32);
+  if (count) {
+    hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32);
+    hipLaunchKernelGGL(pack_data, dim3((unsigned)(w.b.tile_stride - 1), count), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_out32);
+  }
   hipLaunchKernelGGL(pack_frame, dim3(1), dim3(1), 0, s, w.b, count, level, write_header, write_trailer, stream_crc, d_out32, w.scalars);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
