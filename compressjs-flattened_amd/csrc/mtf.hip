@@ -109,33 +109,41 @@ __global__ __launch_bounds__(256) void mtf_seg_scan(MtfBufs mb) {
   }
 }
 __global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
-  __shared__ int keys[256];
+  __shared__ int keys[256];            // sort key of the u-th USED symbol (text uses ~100 of the 256 byte values: the
+  __shared__ uint8_t symof[256];       // rank-by-counting is quadratic in the number of symbols that take part)
+  __shared__ uint8_t uof[256];         // byte value -> used index
   __shared__ uint32_t part[4][256];
-  const uint32_t blk = blockIdx.y, seg = blockIdx.x, H = mb.nheads[blk];
+  const uint32_t blk = blockIdx.y, seg = blockIdx.x, H = mb.nheads[blk], nu = mb.asz[blk];
   const uint32_t nch = (H + MTF_CHUNK - 1) / MTF_CHUNK;
   const uint32_t c0 = seg * MTF_SEG;
   if (c0 >= nch) return;
   const uint32_t c1 = c0 + MTF_SEG < nch ? c0 + MTF_SEG : nch;
   const uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
   uint8_t* lists = mb.lists + (size_t)blk * mb.list_stride;
-  if (threadIdx.x < 256) keys[threadIdx.x] = mb.segkeys[((size_t)blk * mb.seg_stride + seg) * 256 + threadIdx.x];
+  if (threadIdx.x < nu) {
+    const uint8_t sym = mb.alist[(size_t)blk * 256 + threadIdx.x];
+    symof[threadIdx.x] = sym; uof[sym] = (uint8_t)threadIdx.x;
+    keys[threadIdx.x] = mb.segkeys[((size_t)blk * mb.seg_stride + seg) * 256 + sym];
+  }
   __syncthreads();
-  const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const uint32_t d = threadIdx.x & 255u, q = threadIdx.x >> 8, per = (nu + 3u) / 4u;
+  const uint32_t j0 = q * per, j1 = j0 + per < nu ? j0 + per : nu;
   for (uint32_t c = c0; c < c1; c++) {
-    const int kd = keys[d];
-    uint32_t cnt = 0;
-#pragma unroll 8
-    for (int j = 0; j < 64; j++) cnt += keys[q * 64 + j] > kd;
-    part[q][d] = cnt;
+    if (d < nu) {
+      const int kd = keys[d];
+      uint32_t cnt = 0;
+      for (uint32_t j = j0; j < j1; j++) cnt += keys[j] > kd;
+      part[q][d] = cnt;
+    }
     __syncthreads();
-    if (threadIdx.x < 256 && kd >= 0) {
+    if (threadIdx.x < nu) {
       const uint32_t p = part[0][d] + part[1][d] + part[2][d] + part[3][d];
-      lists[(size_t)c * 256 + p] = (uint8_t)d;
+      lists[(size_t)c * 256 + p] = symof[d];
     }
     __syncthreads();
     if (threadIdx.x < MTF_CHUNK) {
       const uint32_t h = c * MTF_CHUNK + threadIdx.x;
-      if (h < H) atomicMax(&keys[hsym[h]], (int)(256 + h));
+      if (h < H) atomicMax(&keys[uof[hsym[h]]], (int)(256 + h));
     }
     __syncthreads();
   }
