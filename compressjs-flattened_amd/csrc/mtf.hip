@@ -236,13 +236,22 @@ __global__ __launch_bounds__(1024) void mtf_emit_tiles(const uint32_t* __restric
   if (WRITE) { for (int i = threadIdx.x; i < 258; i += 1024) freq[i] = 0; __syncthreads(); }
   const uint32_t h0 = base + threadIdx.x * 4;
   uint32_t lit[4], z[4], nd[4], cnt = 0, rk[4];
+  // the four heads of a lane: ranks as one 32-bit load, positions as one 128-bit load (+ the next head's position);
+  // rows of hrank / hpos are 16-element aligned and h0 is a multiple of 4
+  uint32_t rk4 = 0, hp[5] = {0, 0, 0, 0, 0};
+  if (h0 < H) {
+    rk4 = *reinterpret_cast<const uint32_t*>(hrank + h0);
+    const uint4 p4 = *reinterpret_cast<const uint4*>(hpos + h0);
+    hp[0] = p4.x; hp[1] = p4.y; hp[2] = p4.z; hp[3] = p4.w;
+    hp[4] = h0 + 4 < H ? hpos[h0 + 4] : n;
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const uint32_t h = h0 + j;
     lit[j] = z[j] = nd[j] = rk[j] = 0;
     if (h < H) {
-      const uint32_t r = hrank[h];
-      const uint32_t len = (h + 1 < H ? hpos[h + 1] : n) - hpos[h];
+      const uint32_t r = (rk4 >> (8 * j)) & 0xFFu;
+      const uint32_t len = (h + 1 < H ? hp[j + 1] : n) - hp[j];
       lit[j] = r != 0;
       rk[j] = r;
       z[j] = len - lit[j];
