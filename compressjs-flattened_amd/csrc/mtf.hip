@@ -34,11 +34,24 @@ __global__ __launch_bounds__(1024) void mtf_head_tiles(const uint8_t* __restrict
   if (!WRITE) { if (threadIdx.x < 256) used[threadIdx.x] = 0; __syncthreads(); }
   const uint32_t p0 = base + threadIdx.x * 4;
   uint8_t c[4]; uint32_t fm = 0, cnt = 0;
-  uint8_t prev = (p0 > 0 && p0 - 1 < n) ? u[p0 - 1] : 0;
+  uint8_t prev = 0;
+  if (p0 < n) {
+    // bytes p0-1 .. p0+3 from three aligned 32-bit words (block rows start at odd addresses: the lanes' own 4 bytes straddle
+    // two words); the word before the very first byte of U is not touched
+    const uintptr_t a = (uintptr_t)(u + p0);
+    const uint32_t* al = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const bool first = blk == 0 && p0 == 0;
+    const uint32_t wm = first ? 0u : al[-1], w0 = al[0], w1 = sh ? al[1] : 0u;        // al[1] only when the 4 bytes straddle
+    const uint32_t mine = __builtin_amdgcn_alignbyte(w1, w0, sh);                     // bytes p0 .. p0+3
+    prev = (uint8_t)(__builtin_amdgcn_alignbyte(w0, wm, sh) >> 24);                   // byte p0-1
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = (uint8_t)(mine >> (8 * j));
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const uint32_t p = p0 + j;
-    c[j] = p < n ? u[p] : 0;
+    if (p >= n) c[j] = 0;
     if (p < n && (p == 0 || c[j] != prev)) { fm |= 1u << j; cnt++; if (!WRITE) used[c[j]] = 1; }   // every used byte value starts a run
     prev = c[j];
   }
