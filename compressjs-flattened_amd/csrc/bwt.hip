@@ -774,6 +774,36 @@ __global__ __launch_bounds__(256) void bwt_emit(const uint8_t* __restrict__ T, G
                                                 const uint32_t* __restrict__ SA, const uint32_t* __restrict__ R, uint8_t* __restrict__ U, uint32_t Tn) {
   const uint32_t tile = xcd_tile(blockIdx.x, Tn);
   if (tile >= Tn) return;
+  if (cyclic && (((uintptr_t)U | (uintptr_t)SA) & 15u) == 0) {
+    // U is one flat array in sorted-position order (u[p] of block blk is U[blk*stride + p]): four positions per lane,
+    // one 16-byte load of SA, four byte gathers from the block text, one aligned 32-bit store
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const uint64_t a0 = (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u;
+      if (a0 >= M) break;
+      if (a0 + 4 <= M) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 s4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(SA + a0));
+        const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
+        uint32_t outw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint64_t a = a0 + j;
+          const uint32_t blk = (uint32_t)(a / g.stride), n = blk_len(g, blk);
+          const uint8_t* t = T + (size_t)blk * g.stride;
+          outw |= (uint32_t)t[sv[j] ? sv[j] - 1 : n - 1] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(U + a0) = outw;
+      } else {
+        for (uint64_t a = a0; a < M; a++) {
+          const uint32_t blk = (uint32_t)(a / g.stride), n = blk_len(g, blk);
+          const uint32_t s = SA[a];
+          U[a] = T[(size_t)blk * g.stride + (s ? s - 1 : n - 1)];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll 4
   for (int it = 0; it < 16; it++) {
     const uint64_t a = (uint64_t)tile * RS_TILE + (uint32_t)it * 256 + threadIdx.x;
