@@ -132,6 +132,167 @@ __global__ __launch_bounds__(64) void bwtc_fenwick(MtfBufs mb, uint64_t* __restr
   if (lane == 0) nsteps[blk] = n;
 }
 
+// ---------------------------------------------------------------- FenwickModel evaluated 64 symbols at a time
+// Between two rescales the model only counts: every coded symbol adds F_INC to its own frequency, and a symbol whose
+// frequency is zero is announced by the escape symbol first.  So for a chunk of 64 symbols with NO rescale inside,
+// everything a coder step needs is a prefix count over the chunk:
+//   frequency of s at position j      = leaf(s) at the chunk start + F_INC * #{j' < j : s_j' = s}
+//   cumulative frequency below s      = cum(s)  at the chunk start + F_INC * #{j' < j : s_j' < s}
+//   total                             = root    at the chunk start + F_INC * (steps so far)
+//   escape events                     = first occurrences of symbols whose frequency was zero at the chunk start
+// The 64x64 relations are two 64-bit masks per lane (same symbol / smaller symbol), built with 64 readlanes; the counts
+// are popcounts.  The position whose steps make the total reach F_MAX (rescale), and the rare "last unseen symbol"
+// escape, are done one at a time by fm_serial on the same flat leaf array; the chunk continues behind them.
+// The model is kept as flat leaves (packed hi = main count, lo = escape-context count, as in the reference's tree
+// leaves) plus an exclusive prefix array rebuilt per chunk: no tree.
+__device__ __forceinline__ void fm_build_cum(const uint32_t* leaf, uint32_t* cum, int ns) {
+  const int lane = lane_id(), i0 = 5 * lane;
+  uint32_t pre[5], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) { pre[k] = sum; sum += i0 + k < ns ? leaf[i0 + k] : 0u; }
+  const uint32_t ex = wave_incl_sum(sum) - sum;
+#pragma unroll
+  for (int k = 0; k < 5; k++) if (i0 + k <= ns) cum[i0 + k] = ex + pre[k];        // cum[ns] = root
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ void fm_rescale(uint32_t* leaf, int ns, int e) {    // _rescale (:1623-1654) on the flat leaves; e = slot of the escape symbol
+  const int lane = lane_id();
+  bool esc_here = false;
+  for (int i = lane; i < ns; i += 64) {
+    if (i == e) continue;
+    uint32_t prob = leaf[i];
+    if (prob & 0xFFFFu) { esc_here = true; continue; }
+    prob = (prob & 0xFFFEFFFEu) >> 1;
+    if (prob == 0) { prob = 1u; esc_here = true; }
+    leaf[i] = prob;
+  }
+  const bool no_escape = __ballot(esc_here) == 0ull;
+  if (lane == 0) {
+    uint32_t prob = leaf[e];
+    prob = (prob & 0xFFFEFFFEu) >> 1;
+    if (no_escape) prob = 0; else if (prob == 0) prob = 1u << 16;
+    leaf[e] = prob;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+// encode(symbol) for ONE symbol (:1530-1571), any state: escape, last escape, rescales
+__device__ void fm_serial(uint32_t* leaf, uint32_t* cum, int ns, int e, int symbol, uint64_t* out, uint32_t& n) {
+  const int lane = lane_id();
+  fm_build_cum(leaf, cum, ns);
+  uint32_t root = __builtin_amdgcn_readfirstlane(cum[ns]);
+  const uint32_t leafv = __builtin_amdgcn_readfirstlane(leaf[symbol]);
+  const bool esc = (leafv >> 16) == 0;
+  if (esc) {
+    const uint32_t sy_raw = __builtin_amdgcn_readfirstlane(leaf[e]), lt = __builtin_amdgcn_readfirstlane(cum[e]);
+    uint32_t update = F_INC << 16;
+    if ((root & 0xFFFFu) == 1u) update = 0u - sy_raw;          // last escape: zero it out
+    if (lane == 0) { out[n] = (uint64_t)(sy_raw >> 16) | ((uint64_t)(lt >> 16) << 16) | ((uint64_t)(root >> 16) << 32); leaf[e] = sy_raw + update; }
+    n++;
+    __builtin_amdgcn_wave_barrier();
+    root += update;
+    if ((root >> 16) >= F_MAX) fm_rescale(leaf, ns, e);
+    fm_build_cum(leaf, cum, ns);
+    root = __builtin_amdgcn_readfirstlane(cum[ns]);
+    const uint32_t sy2 = __builtin_amdgcn_readfirstlane(leaf[symbol]), lt2 = __builtin_amdgcn_readfirstlane(cum[symbol]);
+    if (lane == 0) { out[n] = (uint64_t)(sy2 & 0xFFFFu) | ((uint64_t)(lt2 & 0xFFFFu) << 16) | ((uint64_t)(root & 0xFFFFu) << 32); leaf[symbol] = sy2 + ((F_INC << 16) - 1u); }
+    n++;
+    __builtin_amdgcn_wave_barrier();
+    root += (F_INC << 16) - 1u;
+    if ((root >> 16) >= F_MAX) fm_rescale(leaf, ns, e);
+  } else {
+    const uint32_t lt = __builtin_amdgcn_readfirstlane(cum[symbol]);
+    if (lane == 0) { out[n] = (uint64_t)(leafv >> 16) | ((uint64_t)(lt >> 16) << 16) | ((uint64_t)(root >> 16) << 32); leaf[symbol] = leafv + (F_INC << 16); }
+    n++;
+    __builtin_amdgcn_wave_barrier();
+    root += F_INC << 16;
+    if ((root >> 16) >= F_MAX) fm_rescale(leaf, ns, e);
+  }
+}
+
+__global__ __launch_bounds__(64) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps, int force_serial) {
+  __shared__ uint32_t leaf[328], cum[328];
+  const uint32_t blk = blockIdx.x;
+  const uint32_t asz = mb.asz[blk], nsym = mb.npos[blk] - 1;      // drop bzip2's EOB
+  const uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
+  uint64_t* out = steps + (size_t)blk * step_stride;
+  const int lane = lane_id();
+  const int ns = (int)asz + 2;
+  // The reference keeps the counts in an implicit binary tree with the leaves at [ns, 2ns): "cumulative frequency below s"
+  // is the sum over the leaves LEFT of s in that tree, and when ns is not a power of two the bottom-level leaves
+  // (symbols >= r0) come first.  All slots below are in that order: slot(s) = (s - r0) mod ns.
+  int dpt = 0; while ((2 << dpt) <= 2 * ns - 1) dpt++;                  // depth of the deepest leaf: floor(log2(2ns - 1))
+  const int r0 = (1 << dpt) - ns, e = ns - 1 - r0;                      // slot of the escape symbol (symbol ns-1)
+  for (int i = lane; i < 328; i += 64) { leaf[i] = i == e ? (F_INC << 16) : i < ns ? 1u : 0u; cum[i] = 0; }
+  __builtin_amdgcn_wave_barrier();
+  uint32_t n = 0;
+  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;       // lanes < lane
+  for (uint32_t base = 0; base < nsym; base += 64) {
+    const uint32_t cnt = __builtin_amdgcn_readfirstlane(nsym - base < 64 ? nsym - base : 64);
+    uint32_t mine = 0xFFFFu;
+    if ((uint32_t)lane < cnt) { const int sy = (int)A[base + lane]; mine = (uint32_t)(sy >= r0 ? sy - r0 : sy + ns - r0); }
+    const uint64_t LTE = __ballot(mine < (uint32_t)e);                  // positions whose slot lies left of the escape symbol
+    // relations inside the chunk: lanes with the same / a smaller symbol (all 64 pairs, any window is a mask away)
+    uint64_t eqm = 0, ltm = 0;
+    for (uint32_t jp = 0; jp < cnt; jp++) {
+      const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)jp);
+      eqm |= sj == mine ? 1ull << jp : 0ull;
+      ltm |= sj < mine ? 1ull << jp : 0ull;
+    }
+    uint32_t start = 0;
+    while (start < cnt) {
+      fm_build_cum(leaf, cum, ns);
+      const uint32_t root = __builtin_amdgcn_readfirstlane(cum[ns]);
+      const uint32_t esc_leaf = __builtin_amdgcn_readfirstlane(leaf[e]);
+      const uint64_t win = (~0ull << start) & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));    // positions [start, cnt)
+      const bool active = (win >> lane) & 1ull;
+      const uint64_t before = below & win;                                                   // positions [start, lane)
+      const uint32_t leafv = active ? leaf[mine] : 0x10000u;
+      const uint32_t cumv = active ? cum[mine] : 0u;
+      const uint32_t eqb = (uint32_t)__builtin_popcountll(eqm & before);
+      const bool escj = active && (leafv >> 16) == 0 && eqb == 0;                            // first occurrence of a zero-count symbol
+      const uint64_t ESCM = __ballot(escj);
+      const uint32_t Eb = (uint32_t)__builtin_popcountll(ESCM & before);
+      const uint32_t rel = (uint32_t)lane - start;
+      const uint32_t through = rel + 1u + Eb + (escj ? 1u : 0u);                             // steps up to and including this position
+      const uint32_t root_hi = root >> 16, root_lo = root & 0xFFFFu;
+      const uint32_t kstar = root_hi >= F_MAX ? 1u : (F_MAX - root_hi + F_INC - 1u) / F_INC;  // the step after which the total reaches F_MAX
+      const bool cut = active && (through >= kstar || (escj && (root_lo - Eb == 1u || (force_serial & 2))));
+      const uint64_t cutm = __ballot(cut);
+      const uint32_t c = (force_serial & 1) ? start : cutm ? (uint32_t)__builtin_ctzll(cutm) : cnt;                       // [start, c) in parallel, c one at a time
+      const uint64_t parw = win & (c == 64 ? ~0ull : ((1ull << c) - 1ull));
+      if ((parw >> lane) & 1ull) {
+        const uint32_t tot = root_hi + F_INC * (rel + Eb);
+        const uint32_t o = n + rel + Eb;
+        if (escj) {
+          const uint32_t esc_hi = (esc_leaf >> 16) + F_INC * Eb;
+          const uint32_t cum_e = (uint32_t)__builtin_amdgcn_readfirstlane(cum[e]);      // (the builtin returns int: shift the unsigned copy)
+          const uint32_t lt_e = (cum_e >> 16) + F_INC * (uint32_t)__builtin_popcountll(LTE & before);
+          out[o] = (uint64_t)esc_hi | ((uint64_t)lt_e << 16) | ((uint64_t)tot << 32);
+          const uint32_t lt_lo = (cumv & 0xFFFFu) - (uint32_t)__builtin_popcountll(ESCM & ltm & before);
+          out[o + 1] = 1ull | ((uint64_t)lt_lo << 16) | ((uint64_t)(root_lo - Eb) << 32);
+        } else {
+          const uint32_t sy = (leafv >> 16) + F_INC * eqb;
+          // counts left of this slot: earlier symbols in lower slots, and the escape symbol's own increments if it lies left
+          const uint32_t lt = (cumv >> 16) + F_INC * ((uint32_t)__builtin_popcountll(ltm & before) + (mine > (uint32_t)e ? Eb : 0u));
+          out[o] = (uint64_t)sy | ((uint64_t)lt << 16) | ((uint64_t)tot << 32);
+        }
+        // the last occurrence of a symbol inside [start, c) writes its new leaf (count so far, escape count 0)
+        const uint64_t later = eqm & parw & ~below & ~(1ull << lane);
+        if (!later) leaf[mine] = ((leafv >> 16) + F_INC * (eqb + 1u)) << 16;
+      }
+      const uint32_t nesc = (uint32_t)__builtin_popcountll(ESCM & parw);
+      if (lane == 0 && nesc) leaf[e] = esc_leaf + ((F_INC * nesc) << 16);
+      n += (c - start) + nesc;
+      __builtin_amdgcn_wave_barrier();
+      if (c < cnt) {
+        fm_serial(leaf, cum, ns, e, __builtin_amdgcn_readlane((int)mine, (int)c), out, n);
+        start = c + 1;
+      } else start = cnt;
+    }
+  }
+  if (lane == 0) nsteps[blk] = n;
+}
+
 // ---------------------------------------------------------------- DefSumModel (levels 1-5), one lane per block
 __global__ __launch_bounds__(64) void bwtc_defsum(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps) {
   __shared__ uint16_t prob[304], esc[304], upd[304];
@@ -277,8 +438,33 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     if (!rc) rc = mtf_run(s, mw, d_U, nb, d_len);
     if (!rc) {
       if (fast) hipLaunchKernelGGL(bwtc_defsum, dim3(nb), dim3(64), 0, s, mw.b, d_steps, step_stride, d_nsteps);
-      else hipLaunchKernelGGL(bwtc_fenwick, dim3(nb), dim3(64), 0, s, mw.b, d_steps, step_stride, d_nsteps);
+      else if (getenv("CJS_BWTC_SERIAL_MODEL")) hipLaunchKernelGGL(bwtc_fenwick, dim3(nb), dim3(64), 0, s, mw.b, d_steps, step_stride, d_nsteps);
+      else hipLaunchKernelGGL(bwtc_fenwick_par, dim3(nb), dim3(64), 0, s, mw.b, d_steps, step_stride, d_nsteps, getenv("CJS_BWTC_FORCE_SERIAL") ? atoi(getenv("CJS_BWTC_FORCE_SERIAL")) : 0);
       if (hipGetLastError() != hipSuccess) rc = CJS_E_HIP;
+      if (!rc && !fast && getenv("CJS_BWTC_CHECK")) {               // debug: the one-symbol-at-a-time kernel must give the same steps
+        uint64_t* d_ref = nullptr; uint32_t* d_nref = nullptr;
+        if (hipMalloc((void**)&d_ref, 8 * (size_t)nb * step_stride) == hipSuccess && hipMalloc((void**)&d_nref, 4 * (size_t)nb) == hipSuccess) {
+          hipLaunchKernelGGL(bwtc_fenwick, dim3(nb), dim3(64), 0, s, mw.b, d_ref, step_stride, d_nref);
+          std::vector<uint32_t> na(nb), nr(nb);
+          (void)hipMemcpyAsync(na.data(), d_nsteps, 4 * (size_t)nb, hipMemcpyDeviceToHost, s);
+          (void)hipMemcpyAsync(nr.data(), d_nref, 4 * (size_t)nb, hipMemcpyDeviceToHost, s);
+          (void)hipStreamSynchronize(s);
+          for (uint32_t k = 0; k < nb; k++) {
+            const uint32_t m = na[k] < nr[k] ? na[k] : nr[k];
+            std::vector<uint64_t> a(m), r(m);
+            if (m) { (void)hipMemcpy(a.data(), d_steps + (size_t)k * step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); (void)hipMemcpy(r.data(), d_ref + (size_t)k * step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); }
+            uint32_t i = 0; while (i < m && a[i] == r[i]) i++;
+            if (i < m || na[k] != nr[k]) {
+              fprintf(stderr, "[cjs bwtc check] block %u: steps %u vs %u, first difference at %u", k, na[k], nr[k], i);
+              for (uint32_t q = i > 2 ? i - 2 : 0; q < i + 3 && q < m; q++) fprintf(stderr, "  [%u] %llx | %llx", q, (unsigned long long)a[q], (unsigned long long)r[q]);
+              fprintf(stderr, "\n");
+              break;
+            }
+          }
+        }
+        if (d_ref) (void)hipFree(d_ref);
+        if (d_nref) (void)hipFree(d_nref);
+      }
     }
     std::vector<uint32_t> h_pidx(nb), h_asz(nb), h_nsteps(nb);
     std::vector<uint8_t> h_alist((size_t)nb * 256);

@@ -309,11 +309,11 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
             long long j = bw.peek(p0, i);
             for (;; i++) {
               if (i > mx) { err = CJS_E_DATA_ERROR; break; }
-              if (j <= (long long)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
+              if (j <= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
               j = (j << 1) | bw.peek(p0 + i, 1);
             }
             if (err) break;
-            j -= (long long)__builtin_amdgcn_readfirstlane(S.base[g][i]);
+            j -= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.base[g][i]);
             if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
             ee = (__builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]) << 5) | (uint32_t)i;
           }
@@ -517,11 +517,11 @@ __global__ __launch_bounds__(128) void bz_decode_block_pipe(const uint8_t* __res
             long long j = bw.peek(p0, i);
             for (;; i++) {
               if (i > mx) { err = CJS_E_DATA_ERROR; break; }
-              if (j <= (long long)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
+              if (j <= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
               j = (j << 1) | bw.peek(p0 + i, 1);
             }
             if (err) break;
-            j -= (long long)__builtin_amdgcn_readfirstlane(S.base[g][i]);
+            j -= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.base[g][i]);
             if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
             ee = (__builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]) << 5) | (uint32_t)i;
           }
