@@ -13,6 +13,8 @@
 #include "mtf.h"
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <mutex>
 #include <vector>
 
 namespace cjs {
@@ -365,6 +367,16 @@ struct HostCoder {                                      // RangeCoder encode sid
     low += tmp;
     if (lt + sy < tot) range = r * sy; else range -= tmp;
   }
+  // same arithmetic with the division replaced by a multiply with floor(2^32 / tot) and one correction: the quotient
+  // sits on the serial (low, range) chain, the reciprocal (looked up by tot, which comes from the step list) does not
+  inline void freq_rcp(uint32_t sy, uint32_t lt, uint32_t tot, const uint32_t* rcp) {
+    normalize();
+    uint32_t r = (uint32_t)(((uint64_t)range * rcp[tot]) >> 32);    // floor(range / tot) or one less (range < 2^32)
+    if (range - r * tot >= tot) r++;
+    const uint32_t tmp = r * lt;
+    low += tmp;
+    if (lt + sy < tot) range = r * sy; else range -= tmp;
+  }
   inline void shift(uint32_t sy, uint32_t lt, int sh) {
     normalize();
     const uint32_t r = range >> sh, tmp = r * lt;
@@ -412,6 +424,8 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
   coder.start(vb[0], 1);                                             // :1700 (the last varint byte is the coder's first byte)
   coder.shift(1, (uint32_t)level, 8);                                // encodeByte(level) :1706
   int rc = 0;
+  const auto T0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   if (nb) {
     const uint32_t n_last = (uint32_t)(n - (size_t)(nb - 1) * bs);
     Arena arena;
@@ -473,8 +487,26 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     if (!rc && hipMemcpyAsync(h_nsteps.data(), d_nsteps, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
     if (!rc && hipMemcpyAsync(h_alist.data(), mw.b.alist, (size_t)nb * 256, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
     if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
-    std::vector<uint64_t> h_steps;
+    const double ms_gpu = since(T0);
+    const auto T1 = std::chrono::steady_clock::now();
+    // reciprocals floor(2^32 / tot) for every total a step can carry (17 bits); tot < 2 keeps the division
+    static std::vector<uint32_t> rcp;
+    static std::once_flag rcp_once;
+    std::call_once(rcp_once, [] { rcp.assign(1u << 17, 0u); for (uint32_t t = 2; t < (1u << 17); t++) rcp[t] = (uint32_t)((1ull << 32) / t); });
+    // the steps of block k+1 travel (pinned buffer, copy stream) while block k goes through the coder
+    uint64_t* h_buf[2] = {nullptr, nullptr};
+    hipStream_t cs = nullptr; hipEvent_t cev[2] = {nullptr, nullptr};
+    if (!rc && (hipHostMalloc((void**)&h_buf[0], 8 * step_stride) != hipSuccess || hipHostMalloc((void**)&h_buf[1], 8 * step_stride) != hipSuccess ||
+                hipStreamCreate(&cs) != hipSuccess || hipEventCreateWithFlags(&cev[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&cev[1], hipEventDisableTiming) != hipSuccess)) rc = CJS_E_HIP;
+    auto fetch = [&](uint32_t k) {
+      if (h_nsteps[k] && hipMemcpyAsync(h_buf[k & 1], d_steps + (size_t)k * step_stride, 8 * (size_t)h_nsteps[k], hipMemcpyDeviceToHost, cs) != hipSuccess) return (int)CJS_E_HIP;
+      return hipEventRecord(cev[k & 1], cs) == hipSuccess ? 0 : (int)CJS_E_HIP;
+    };
+    if (!rc && nb) rc = fetch(0);
     for (uint32_t k = 0; k < nb && !rc; k++) {
+      if (k + 1 < nb) rc = fetch(k + 1);
+      if (rc) break;
       const uint32_t length = lens[k];
       if (length == bs) coder.freq(1, 0, 3);                         // "full size block" :1734
       else { coder.freq(1, 1, 3); logdist(coder, (int)bs, length); } // "short block" :1737-1738
@@ -489,14 +521,21 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
         if (i >= 256) coder.shift(1, tree[i] ? 1 : 0, 1);
         else coder.freq(1, tree[i] == 0 ? 0u : tree[i] == full ? 2u : 1u, 3);
       }
-      h_steps.resize(h_nsteps[k]);
-      if (h_nsteps[k] && hipMemcpy(h_steps.data(), d_steps + (size_t)k * step_stride, 8 * (size_t)h_nsteps[k], hipMemcpyDeviceToHost) != hipSuccess) { rc = CJS_E_HIP; break; }
+      if (hipEventSynchronize(cev[k & 1]) != hipSuccess) { rc = CJS_E_HIP; break; }
+      const uint64_t* h_steps = h_buf[k & 1];
+      const uint32_t* rc_tab = rcp.data();
       for (uint32_t i = 0; i < h_nsteps[k]; i++) {                    // the serial tail
         const uint64_t st = h_steps[i];
         const uint32_t sy = (uint32_t)(st & 0xFFFF), lt = (uint32_t)((st >> 16) & 0xFFFF), tot = (uint32_t)((st >> 32) & 0x1FFFF);
-        if (st & STEP_SHIFT_FLAG) coder.shift(sy, lt, (int)tot); else coder.freq(sy, lt, tot);
+        if (st & STEP_SHIFT_FLAG) coder.shift(sy, lt, (int)tot);
+        else if (tot >= 2) coder.freq_rcp(sy, lt, tot, rc_tab);
+        else coder.freq(sy, lt, tot);
       }
     }
+    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwtc] workspace + H2D + BWT + MTF + model %.1f ms, range coder over the step lists (host, serial) %.1f ms\n", ms_gpu, since(T1));
+    if (cs) (void)hipStreamSynchronize(cs);
+    for (int q = 0; q < 2; q++) { if (cev[q]) (void)hipEventDestroy(cev[q]); if (h_buf[q]) (void)hipHostFree(h_buf[q]); }
+    if (cs) (void)hipStreamDestroy(cs);
     if (s) (void)hipStreamDestroy(s);
     if (bw.h_counters) (void)hipHostFree(bw.h_counters);
     arena.destroy();
