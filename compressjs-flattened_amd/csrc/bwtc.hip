@@ -348,18 +348,37 @@ __global__ __launch_bounds__(64) void bwtc_defsum(MtfBufs mb, uint64_t* __restri
 namespace {
 
 struct HostCoder {                                      // RangeCoder encode side (J/BWTC_joined_.js:40-153)
-  std::vector<uint8_t>& out;
+  std::vector<uint8_t>& out;                            // bytes [0, len) are output; the vector is kept larger (reserve())
+  uint8_t* data = nullptr;
+  size_t len = 0;
   uint32_t low = 0, range = 0x80000000u, help = 0, bytecount = 0;
   int buffer = 0;
-  explicit HostCoder(std::vector<uint8_t>& o) : out(o) {}
+  explicit HostCoder(std::vector<uint8_t>& o) : out(o) { len = o.size(); reserve(4096); }
+  void reserve(size_t extra) {                          // room for `extra` more bytes (a coder step emits at most 3)
+    if (len + extra > out.size()) out.resize(std::max(out.size() * 2, len + extra));
+    data = out.data();
+  }
+  inline void emit(uint8_t b) { data[len++] = b; }
   void start(int c, uint32_t initlen) { low = 0; range = 0x80000000u; buffer = c; help = 0; bytecount = initlen; }
   inline void normalize() {
     while (range <= 0x00800000u) {
-      if (low < (0xFFu << 23)) { out.push_back((uint8_t)buffer); for (; help; help--) out.push_back(0xFF); buffer = (low >> 23) & 0xFF; }
-      else if (low & 0x80000000u) { out.push_back((uint8_t)(buffer + 1)); for (; help; help--) out.push_back(0x00); buffer = (low >> 23) & 0xFF; }
+      if (low < (0xFFu << 23)) { emit((uint8_t)buffer); for (; help; help--) emit(0xFF); buffer = (low >> 23) & 0xFF; }
+      else if (low & 0x80000000u) { emit((uint8_t)(buffer + 1)); for (; help; help--) emit(0x00); buffer = (low >> 23) & 0xFF; }
       else help++;
       range <<= 8; low = (low << 8) & 0x7FFFFFFFu; bytecount++;
     }
+  }
+  // normalize() for the step loop: whether a byte leaves is a coin flip per step, so the usual case (at most one
+  // byte, no pending carry bytes, no carry) is written without a branch: unconditional store, conditional advance
+  inline void normalize_step() {
+    const uint32_t need = range <= 0x00800000u;
+    if (__builtin_expect((range <= 0x00008000u) | (need & (uint32_t)((low >= (0xFFu << 23)) | (help != 0))), 0)) { normalize(); return; }
+    data[len] = (uint8_t)buffer;
+    len += need;
+    buffer = need ? (int)((low >> 23) & 0xFF) : buffer;
+    low = need ? (low << 8) & 0x7FFFFFFFu : low;
+    range = need ? range << 8 : range;
+    bytecount += need;
   }
   inline void freq(uint32_t sy, uint32_t lt, uint32_t tot) {
     normalize();
@@ -367,15 +386,16 @@ struct HostCoder {                                      // RangeCoder encode sid
     low += tmp;
     if (lt + sy < tot) range = r * sy; else range -= tmp;
   }
-  // same arithmetic with the division replaced by a multiply with floor(2^32 / tot) and one correction: the quotient
-  // sits on the serial (low, range) chain, the reciprocal (looked up by tot, which comes from the step list) does not
-  inline void freq_rcp(uint32_t sy, uint32_t lt, uint32_t tot, const uint32_t* rcp) {
-    normalize();
-    uint32_t r = (uint32_t)(((uint64_t)range * rcp[tot]) >> 32);    // floor(range / tot) or one less (range < 2^32)
-    if (range - r * tot >= tot) r++;
+  // same arithmetic with the division replaced by a multiply with a 64-bit reciprocal: the quotient sits on the serial
+  // (low, range) chain, the reciprocal (looked up by tot, which comes from the step list) does not
+  inline void freq_rcp(uint32_t sy, uint32_t lt, uint32_t tot, const uint64_t* rcp) {
+    normalize_step();
+    // rcp[tot] = floor(2^64 / tot) + 1: the high half of range * rcp is floor(range / tot) exactly (range < 2^32, tot < 2^17:
+    // range * (rcp*tot - 2^64) < 2^49 < 2^64), so no correction step sits on the chain
+    const uint32_t r = (uint32_t)(((unsigned __int128)range * rcp[tot]) >> 64);
     const uint32_t tmp = r * lt;
     low += tmp;
-    if (lt + sy < tot) range = r * sy; else range -= tmp;
+    range = (lt + sy < tot) ? r * sy : range - tmp;
   }
   inline void shift(uint32_t sy, uint32_t lt, int sh) {
     normalize();
@@ -384,14 +404,16 @@ struct HostCoder {                                      // RangeCoder encode sid
     if ((lt + sy) >> sh) range -= tmp; else range = r * sy;
   }
   void finish() {
+    reserve(help + 16);
     normalize();
     bytecount += 5;
     uint32_t tmp = low >> 23;
     if ((low & 0x7FFFFFu) >= ((bytecount & 0xFFFFFFu) >> 1)) tmp++;
-    if (tmp > 0xFF) { out.push_back((uint8_t)(buffer + 1)); for (; help; help--) out.push_back(0x00); }
-    else { out.push_back((uint8_t)buffer); for (; help; help--) out.push_back(0xFF); }
-    out.push_back((uint8_t)(tmp & 0xFF));
-    out.push_back((uint8_t)((bytecount >> 16) & 0xFF)); out.push_back((uint8_t)((bytecount >> 8) & 0xFF)); out.push_back((uint8_t)(bytecount & 0xFF));
+    if (tmp > 0xFF) { emit((uint8_t)(buffer + 1)); for (; help; help--) emit(0x00); }
+    else { emit((uint8_t)buffer); for (; help; help--) emit(0xFF); }
+    emit((uint8_t)(tmp & 0xFF));
+    emit((uint8_t)((bytecount >> 16) & 0xFF)); emit((uint8_t)((bytecount >> 8) & 0xFF)); emit((uint8_t)(bytecount & 0xFF));
+    out.resize(len);
   }
 };
 int fls32(uint32_t v) { int r = 0; while (v) { r++; v >>= 1; } return r; }
@@ -489,10 +511,10 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
     const double ms_gpu = since(T0);
     const auto T1 = std::chrono::steady_clock::now();
-    // reciprocals floor(2^32 / tot) for every total a step can carry (17 bits); tot < 2 keeps the division
-    static std::vector<uint32_t> rcp;
+    // reciprocals floor(2^64 / tot) + 1 for every total a step can carry (17 bits); tot < 2 keeps the division
+    static std::vector<uint64_t> rcp;
     static std::once_flag rcp_once;
-    std::call_once(rcp_once, [] { rcp.assign(1u << 17, 0u); for (uint32_t t = 2; t < (1u << 17); t++) rcp[t] = (uint32_t)((1ull << 32) / t); });
+    std::call_once(rcp_once, [] { rcp.assign(1u << 17, 0ull); for (uint32_t t = 2; t < (1u << 17); t++) rcp[t] = (uint64_t)(((unsigned __int128)1 << 64) / t) + 1; });
     // the steps of block k+1 travel (pinned buffer, copy stream) while block k goes through the coder
     uint64_t* h_buf[2] = {nullptr, nullptr};
     hipStream_t cs = nullptr; hipEvent_t cev[2] = {nullptr, nullptr};
@@ -507,6 +529,7 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     for (uint32_t k = 0; k < nb && !rc; k++) {
       if (k + 1 < nb) rc = fetch(k + 1);
       if (rc) break;
+      coder.reserve(3 * (size_t)h_nsteps[k] + coder.help + 4096);      // everything this block can emit
       const uint32_t length = lens[k];
       if (length == bs) coder.freq(1, 0, 3);                         // "full size block" :1734
       else { coder.freq(1, 1, 3); logdist(coder, (int)bs, length); } // "short block" :1737-1738
@@ -523,7 +546,7 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
       }
       if (hipEventSynchronize(cev[k & 1]) != hipSuccess) { rc = CJS_E_HIP; break; }
       const uint64_t* h_steps = h_buf[k & 1];
-      const uint32_t* rc_tab = rcp.data();
+      const uint64_t* rc_tab = rcp.data();
       for (uint32_t i = 0; i < h_nsteps[k]; i++) {                    // the serial tail
         const uint64_t st = h_steps[i];
         const uint32_t sy = (uint32_t)(st & 0xFFFF), lt = (uint32_t)((st >> 16) & 0xFFFF), tot = (uint32_t)((st >> 32) & 0x1FFFF);
@@ -541,6 +564,7 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     arena.destroy();
   }
   if (rc) return rc;
+  coder.reserve(coder.help + 64);
   coder.freq(1, 2, 3);                                               // "no more blocks" :1823
   coder.finish();
   uint8_t* host = (uint8_t*)malloc(o.size() ? o.size() : 1);
