@@ -124,7 +124,11 @@ static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, l
   if (((uintptr_t)d_out & 3) != 0) return CJS_E_INVALID_ARG;
   CJS_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  struct EvPair {                                        // whole-call timing events; released on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } evp;
+  hipEvent_t &ev0 = evp.a, &ev1 = evp.b;
   if (st) { memset(st, 0, sizeof *st); CJS_HIP_TRY(hipEventCreate(&ev0)); CJS_HIP_TRY(hipEventCreate(&ev1)); (void)hipEventRecord(ev0, s); }
   uint32_t nb = 0;
   if (st) c->timer.start();
@@ -184,7 +188,6 @@ static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, l
     float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1);
     st->ms_total = ms;
     st->blocks = cnt; st->bytes_in = n; st->bytes_out = (*out_bits + 7) / 8;
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   }
   return 0;
 }
