@@ -4,6 +4,7 @@
 #include "rle1.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 using namespace cjs;
@@ -41,6 +42,54 @@ const char* cjs_strerror(int code) {
 }  // extern "C"
 
 namespace cjs {
+
+// ---- DevPool (see cjs_internal.h)
+namespace {
+struct PoolBuf { void* p; size_t bytes; int device; bool busy; };
+std::mutex g_pool_mu;
+std::vector<PoolBuf> g_pool;
+}  // namespace
+void* DevPool::take(size_t bytes) {
+  if (!bytes) bytes = 4;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    PoolBuf* best = nullptr;
+    for (auto& b : g_pool) if (!b.busy && b.device == dev && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) { best->busy = true; return best->p; }
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    trim();                                              // cached-but-idle buffers may be what is in the way
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  g_pool.push_back(PoolBuf{p, bytes, dev, true});
+  return p;
+}
+void DevPool::give(void* p) {
+  if (!p) return;
+  static const bool no_cache = getenv("CJS_NO_CTX_CACHE") != nullptr;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (size_t i = 0; i < g_pool.size(); i++) if (g_pool[i].p == p) {
+    if (no_cache) { (void)hipFree(p); g_pool.erase(g_pool.begin() + (long)i); }
+    else g_pool[i].busy = false;
+    return;
+  }
+  (void)hipFree(p);                                      // not ours: plain buffer
+}
+void DevPool::trim() {
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (size_t i = 0; i < g_pool.size();) {
+    if (g_pool[i].busy) { i++; continue; }
+    if (hipSetDevice(g_pool[i].device) == hipSuccess) (void)hipFree(g_pool[i].p);
+    g_pool.erase(g_pool.begin() + (long)i);
+  }
+  if (have) (void)hipSetDevice(cur);
+}
 
 int select_device(const cjs_opts* opts) {
   int n = 0;

@@ -47,6 +47,15 @@ struct EventTimer {   // accumulates device time of bracketed regions on one str
   double stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 };
 
+// Per-device cache of device buffers for the host-buffer entry points (hipMalloc / hipFree of the multi-GB scratch of
+// one call cost milliseconds): take() hands out the smallest cached free buffer that is large enough or allocates one,
+// give() returns it to the cache, trim() frees everything cached (cjs_trim; CJS_NO_CTX_CACHE=1 makes give() free at once).
+struct DevPool {
+  static void* take(size_t bytes);
+  static void give(void* p);
+  static void trim();
+};
+
 constexpr uint32_t RS_TILE = 4096;   // radix-sort tile (256 threads x 16 keys)
 
 // Workspace of the suffix sorter for up to `cap` suffixes (all blocks of a batch together).

@@ -929,8 +929,9 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   const uint32_t cand_cap = (uint32_t)(n / 64 + 1024);
   int rc = 0;
   std::vector<void*> to_free;
-  auto dmalloc = [&](void** p, size_t bytes) { if (hipMalloc(p, bytes ? bytes : 4) != hipSuccess) return CJS_E_OUT_OF_MEMORY; to_free.push_back(*p); return 0; };
-  auto cleanup = [&]() { for (void* p : to_free) (void)hipFree(p); if (s) (void)hipStreamDestroy(s); };
+  // scratch comes from the per-device buffer cache (kept between calls; cjs_trim() frees it)
+  auto dmalloc = [&](void** p, size_t bytes) { *p = DevPool::take(bytes); if (!*p) return (int)CJS_E_OUT_OF_MEMORY; to_free.push_back(*p); return 0; };
+  auto cleanup = [&]() { if (s) (void)hipStreamSynchronize(s); for (void* p : to_free) DevPool::give(p); if (s) (void)hipStreamDestroy(s); };
   if (hipStreamCreate(&s) != hipSuccess) return CJS_E_HIP;
   if (!rc) rc = dmalloc((void**)&d_in, n + 16);
   if (!rc) rc = dmalloc((void**)&d_cand, sizeof(Cand) * cand_cap);

@@ -342,6 +342,7 @@ extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_
 }
 
 extern "C" void cjs_trim(void) {
+  DevPool::trim();
   int cur = 0;
   const bool have = hipGetDevice(&cur) == hipSuccess;
   for (int d = 0; d < MAX_CACHED_DEVICES; d++) {
