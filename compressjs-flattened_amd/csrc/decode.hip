@@ -698,15 +698,61 @@ __global__ __launch_bounds__(256) void ib_walk1(const uint32_t* __restrict__ dbu
     spl_next[(size_t)blockIdx.y * spl_stride + sidx] = cur >= b.count ? SPL_END : (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
   }
 }
-// rank the splitter chain from `start`: spl_rank[s] = number of output positions before splitter s's segment
-__global__ void ib_rank(const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t spl_stride, const uint32_t* __restrict__ spl_next,
-                        const uint32_t* __restrict__ spl_steps, uint32_t* __restrict__ spl_rank, int32_t* __restrict__ err) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+// rank the splitter chain from `start`: spl_rank[s] = number of output positions before splitter s's segment.
+// One workgroup per block.  The chain is a list of <= 7034 nodes (a cycle through the start node for a cyclic BWT): the
+// edge back into the first node is cut and the suffix sums of the segment lengths come from pointer jumping in LDS
+// (13 rounds) instead of 7000 dependent loads; rank = total - suffix sum.  If the total is not the block length the
+// permutation has a short cycle (periodic block) and lane 0 walks the chain the slow way, as the reference would.
+constexpr uint32_t IBR_MAX = 7104;       // >= 900000 / SPL + 2
+__global__ __launch_bounds__(1024) void ib_rank(const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t spl_stride, const uint32_t* __restrict__ spl_next,
+                                                const uint32_t* __restrict__ spl_steps, uint32_t* __restrict__ spl_rank, int32_t* __restrict__ err) {
+  __shared__ uint32_t nxt[IBR_MAX], dst[IBR_MAX];
+  __shared__ uint32_t s_total;
+  const uint32_t k = blockIdx.x;
   if (k >= nblocks) return;
   const IbBlock b = blocks[k];
   const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;
   const uint32_t* nx = spl_next + (size_t)k * spl_stride; const uint32_t* st = spl_steps + (size_t)k * spl_stride;
   uint32_t* rk = spl_rank + (size_t)k * spl_stride;
+  bool fast = nspl <= IBR_MAX;
+  if (fast) {
+    const uint32_t entry = nspl - 1;
+    const bool alias = st[entry] == 0;                 // start % SPL == 0: the start entry only points at the regular splitter
+    const uint32_t head = alias ? nx[entry] : entry;
+    for (uint32_t i = threadIdx.x; i < nspl; i += 1024) {
+      uint32_t n = nx[i];
+      if (n == head && !(alias && i == entry)) n = SPL_END;       // the edge that closes the cycle
+      if (n != SPL_END && n >= nspl) n = SPL_END;
+      nxt[i] = n; dst[i] = st[i];
+    }
+    __syncthreads();
+    for (uint32_t span = 1; span < nspl; span <<= 1) {
+      uint32_t nn[7], dd[7];
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        const uint32_t i = threadIdx.x + 1024u * q;
+        nn[q] = SPL_END; dd[q] = 0;
+        if (i < nspl) { const uint32_t n = nxt[i]; if (n != SPL_END) { nn[q] = nxt[n]; dd[q] = dst[n]; } else nn[q] = SPL_END; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        const uint32_t i = threadIdx.x + 1024u * q;
+        if (i < nspl && nxt[i] != SPL_END) { dst[i] += dd[q]; nxt[i] = nn[q]; }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) s_total = dst[entry];
+    __syncthreads();
+    const uint32_t total = s_total;
+    if (total == b.count) {
+      for (uint32_t i = threadIdx.x; i < nspl; i += 1024) rk[i] = total - dst[i];
+      if (threadIdx.x == 0) err[k] = (int32_t)total;
+      return;
+    }
+    fast = false;
+  }
+  if (threadIdx.x != 0) return;
   for (uint32_t i = 0; i < nspl; i++) rk[i] = 0xFFFFFFFFu;
   uint32_t cur = nspl - 1, done = 0;
   // the start splitter may alias a regular one (start % SPL == 0): its entry has steps 0 and points at it
@@ -889,7 +935,7 @@ int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32
   uint32_t* d_dbuf = cur ? d_key0 : d_key1;
   hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_T, stride, d_blocks, sval, d_dbuf);
   hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 1);
-  hipLaunchKernelGGL(ib_rank, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
+  hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
   hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_out, 1);
   std::vector<int32_t> errs(nb);
   if (hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
@@ -1057,7 +1103,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   (void)skey;
   hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, d_tt, dbuf_size, d_blocks, sval, d_dbuf);
   hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 0);
-  hipLaunchKernelGGL(ib_rank, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
+  hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
   hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_w, 0);
   hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, d_blocks, d_err, d_w);
   hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_w, d_blocks, (uint8_t*)nullptr, 0);
