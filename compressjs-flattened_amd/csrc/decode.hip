@@ -11,8 +11,8 @@
 //                        2^-48 candidate inside payload bits is simply never reached), folds CRCs;
 //   4. inverse BWT       T vector by a stable radix pass keyed (block, byte) (:1677-1690), then the LF walk
 //                        (:1732-1737) — n dependent gathers — made k-way parallel by splitter list ranking:
-//                        every 128th slot is a splitter, lanes walk to the next splitter, one lane per block
-//                        ranks the splitters, lanes re-walk writing bytes at their final offsets;
+//                        every 128th slot is a splitter, lanes walk to the next splitter, one workgroup per block
+//                        ranks the splitters (pointer jumping in LDS), lanes re-walk writing bytes at their final offsets;
 //   5. RLE1 expansion    (:1738-1753) parsed in parallel: a count byte follows 4 equal literals; inside a
 //                        stretch of equal bytes the literal/count phase has period 5 and the only carried
 //                        state (does the stretch start with a count byte?) is a 2-state function scan;
