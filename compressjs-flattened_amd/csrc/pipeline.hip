@@ -240,7 +240,9 @@ static void run_shard(Shard* sh, const uint8_t* in, size_t n, int level, long ma
 
 // Multi-GPU host path: blocks are dealt in contiguous ranges to per-GPU worker threads; the only
 // cross-shard data are (bit length, block CRCs).  The host funnel-shifts the bit strings into one stream.
-static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshards, uint8_t** out, size_t* out_n) {
+// max_parallel = shards in flight at a time (0 = all): one per GPU bounds the workspace when the ranges are only there to
+// cut a very large input into pieces (each piece's workspace is ~70 B per byte of its blocks)
+static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshards, uint8_t** out, size_t* out_n, uint32_t max_parallel = 0) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CJS_E_NO_DEVICE;
   const uint32_t cap = (uint32_t)level * 100000u - 19u;
@@ -258,8 +260,12 @@ static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshar
     sh[i].count = std::min<long>(share, total - sh[i].first);
   }
   (void)cap;
-  for (uint32_t i = 0; i < nshards; i++) th.emplace_back(run_shard, &sh[i], in, n, level, share > 0 ? share : 1);
-  for (auto& t : th) t.join();
+  const uint32_t par = max_parallel ? max_parallel : nshards;
+  for (uint32_t i0 = 0; i0 < nshards; i0 += par) {
+    th.clear();
+    for (uint32_t i = i0; i < nshards && i < i0 + par; i++) th.emplace_back(run_shard, &sh[i], in, n, level, share > 0 ? share : 1);
+    for (auto& t : th) t.join();
+  }
   uint64_t total_bits = 32 + 80;
   for (auto& x : sh) { if (x.rc) return x.rc; total_bits += x.bits; }
   const size_t len = (size_t)((total_bits + 7) / 8);
@@ -293,6 +299,16 @@ extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_
   uint32_t nshards = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->n_devices : 0;
   if (const char* e = getenv("CJS_DEVICES")) nshards = (uint32_t)atoi(e);   // lets JS / Python callers shard without an opts struct
   if (nshards > 1 && n > 0) return compress_multi(in, n, level, nshards > 64 ? 64 : nshards, out, out_n);
+  {
+    // very large inputs: block ranges one after the other per GPU, so that the workspace stays bounded (CJS_CHUNK_BYTES, default 2 GiB)
+    static const size_t chunk = getenv("CJS_CHUNK_BYTES") ? (size_t)strtoull(getenv("CJS_CHUNK_BYTES"), nullptr, 10) : ((size_t)2 << 30);
+    if (chunk && n > chunk) {
+      const size_t pieces = (n + chunk / 2 - 1) / (chunk / 2 ? chunk / 2 : 1);
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CJS_E_NO_DEVICE;
+      return compress_multi(in, n, level, (uint32_t)(pieces > 4096 ? 4096 : pieces), out, out_n, 1);
+    }
+  }
   // The workspace (~70 B per input byte), the staging buffers and the streams are kept per device between calls
   // (creating and freeing them costs more than compressing 100 MB); cjs_trim() or CJS_NO_CTX_CACHE=1 gives them back.
   int dev = 0;

@@ -257,6 +257,22 @@ def test_cached_workspace_across_calls(hip, oracle):
     assert rc2 == 0 and np.array_equal(out, oracle.bzip2_compress(recipes.textgen(50000, 27), 9)[1])
 
 
+def test_chunked_large_input_path_is_bit_exact(oracle):
+    # inputs above CJS_CHUNK_BYTES are compressed as block ranges one after the other (bounded workspace) and stitched
+    # on the host: forced here with a tiny threshold (the variable is read once per process, hence the subprocess)
+    data = recipes.textgen(3000000, 12)
+    rc, want = oracle.bzip2_compress(data, 2)
+    import subprocess, sys as _sys
+    code = ("import sys; sys.path.insert(0, 'tests'); import torch, support, recipes, numpy as np; "
+            "d = recipes.textgen(3000000, 12); rc, out = support.HipLib().bzip2_compress(d, 2); "
+            "print(rc, support.sha256(out))")
+    env = dict(os.environ, CJS_CHUNK_BYTES="500000")
+    out = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rc_s, sha = out.stdout.split()
+    assert rc == 0 and rc_s == "0" and sha == support.sha256(want)
+
+
 def test_onesweep_variant_is_bit_exact(hip, oracle, monkeypatch):
     # the opt-in look-back radix passes must give the same stream
     data = recipes.textgen(2500000, 4)
