@@ -2,12 +2,24 @@
 // stage-level entry points.  No CPU fallback: without a HIP device every call fails loudly.
 #include "cjs_internal.h"
 #include "rle1.h"
+#include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <vector>
 
 using namespace cjs;
+
+// detail text of the last failing call on this thread: the reference's `optDetail` (J/Bzip2_joined_.js:1385-1391)
+namespace cjs {
+static thread_local char g_detail[192] = {0};
+void clear_detail() { g_detail[0] = 0; }
+void set_detail(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(g_detail, sizeof g_detail, fmt, ap);
+  va_end(ap);
+}
+}  // namespace cjs
 
 extern "C" {
 
@@ -20,6 +32,8 @@ int cjs_device_count(void) {
 }
 
 void cjs_free(void* p) { free(p); }
+
+const char* cjs_last_error_detail(void) { return g_detail; }
 
 const char* cjs_strerror(int code) {
   switch (code) {

@@ -16,6 +16,7 @@
 #include "cjs_internal.h"
 #include "prims.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace cjs {
 
@@ -52,7 +53,11 @@ __device__ __forceinline__ TileRef tile_ref(const SegGeom& sg, uint32_t tile) {
 // Key source of the first pass of round 1: keys are made on the fly from the block bytes (no key array is ever
 // written for them).  key = leading nsym symbols | block parity above them (adjacent blocks must not compare equal);
 // cyclic: bytes, wrapping; sentinel: 9-bit symbols byte+1, 0 = past the end.  value = position in the block.
-struct GenSrc { const uint8_t* T; int cyclic, nsym; };
+struct GenSrc { const uint8_t* T; int cyclic, nsym, packed; };
+// packed records (cyclic round 1, CJS_R1_PACKED): ONE u64 per suffix = 5 leading bytes (bits 63..24) | block parity (bit 20) |
+// position in the block (bits 19..0): a radix pass moves 8 B per suffix each way instead of 12, and there is no value array
+constexpr int PK_SHIFT = 20, PK_KEY_LO = 24;
+constexpr uint32_t PK_POS_MASK = (1u << PK_SHIFT) - 1u;
 constexpr uint32_t GEN_PAD = 8;
 // stages the tile's bytes (+GEN_PAD lookahead) in LDS; returns the byte offset of the tile's first byte inside tb (< 4):
 // tiles that do not touch the end of their block are copied as aligned 32-bit words from the aligned-down address
@@ -81,6 +86,7 @@ __device__ __forceinline__ uint64_t gen_key(const GenSrc& gs, const SegGeom& sg,
   uint64_t k = 0;
   if (gs.cyclic) {
     k = ((uint64_t)__builtin_bswap32(lo) << 24) | (uint64_t)(__builtin_bswap32(hi) >> 8);     // 7 bytes, first byte on top
+    if (gs.packed) return ((k >> 16) << PK_KEY_LO) | ((uint64_t)(t.seg & 1u) << PK_SHIFT) | (uint64_t)(t.off + loc);
     k >>= 8 * (7 - gs.nsym);
     k |= (uint64_t)(t.seg & 1u) << (8 * gs.nsym);
   } else {
@@ -92,13 +98,17 @@ __device__ __forceinline__ uint64_t gen_key(const GenSrc& gs, const SegGeom& sg,
   return k;
 }
 
+// Per-tile digit counts, tile-major: hist[tile * 256 + digit] (one coalesced 1 KB row per workgroup; the digit-major
+// layout of round 1 cost a 64-byte memory transaction per 4-byte counter on both sides).  Text digits are heavily
+// skewed (a few byte values take most of the counts), so every wave counts into 8 sub-histograms picked by lane & 7:
+// the same-address serialisation of the LDS atomics drops 8-fold.
 template <typename K, bool GEN>
 __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGeom sg, GenSrc gs, int shift,
                                                uint32_t* __restrict__ hist, uint32_t T) {
-  __shared__ uint32_t h[4][256];
+  __shared__ uint32_t h[4][8][256];
   __shared__ __attribute__((aligned(16))) uint8_t tb[GEN ? RS_TILE + GEN_PAD + 16 : 16];
-  const int tid = threadIdx.x, w = tid >> 6;
-  for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
+  const int tid = threadIdx.x, w = tid >> 6, sub = tid & 7;
+  for (int i = tid; i < 4 * 8 * 256; i += 256) (&h[0][0][0])[i] = 0;
   const uint32_t tile = blockIdx.x;
   const TileRef t = tile_ref(sg, tile);
   uint32_t tb0 = 0;
@@ -109,27 +119,49 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
     const uint32_t loc = (uint32_t)it * 256 + tid;
     if (loc < t.nvalid) {
       const uint64_t k = GEN ? gen_key(gs, sg, t, tb, tb0, loc) : (uint64_t)keys[t.base + loc];
-      atomicAdd(&h[w][(uint32_t)(k >> shift) & 255u], 1u);
+      atomicAdd(&h[w][sub][(uint32_t)(k >> shift) & 255u], 1u);
     }
   }
   __syncthreads();
-  hist[(size_t)tid * T + tile] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) c += (&h[0][0][0])[i * 256 + tid];
+  hist[(size_t)tile * 256 + tid] = c;
 }
 
-// one workgroup per (digit value, segment): exclusive scan of that digit's per-tile counts inside the segment
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void rs_scan_bins(uint32_t* __restrict__ hist, uint32_t T, uint32_t tps, uint32_t* __restrict__ bintot) {
-  __shared__ uint32_t sm[16];
-  uint32_t* p = hist + (size_t)blockIdx.x * T + (size_t)blockIdx.y * tps;
+// one workgroup per segment: exclusive scan over the segment's tiles of every digit's count (thread = digit; the rows are
+// read coalesced and the loads of a batch are independent, only the running sums are a chain); digit totals -> bintot
+__global__ __launch_bounds__(256) void rs_scan_bins(uint32_t* __restrict__ hist, uint32_t tps, uint32_t* __restrict__ bintot) {
+  uint32_t* p = hist + (size_t)blockIdx.x * tps * 256 + threadIdx.x;
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < tps; base += BLOCK) {
-    uint32_t i = base + threadIdx.x;
-    uint32_t v = i < tps ? p[i] : 0u, total;
-    uint32_t ex = block_excl_sum<BLOCK>(v, sm, total);
-    if (i < tps) p[i] = carry + ex;
-    carry += total;
+  uint32_t i = 0;
+  for (; i + 8 <= tps; i += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = p[(size_t)(i + j) * 256];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { p[(size_t)(i + j) * 256] = carry; carry += v[j]; }
   }
-  if (threadIdx.x == 0) bintot[(size_t)blockIdx.y * 256 + blockIdx.x] = carry;
+  for (; i < tps; i++) { const uint32_t v = p[(size_t)i * 256]; p[(size_t)i * 256] = carry; carry += v; }
+  bintot[(size_t)blockIdx.x * 256 + threadIdx.x] = carry;
+}
+// plain (one-segment) sorts have up to tens of thousands of tiles: three-phase scan, chunks of SB_CHUNK tiles
+constexpr uint32_t SB_CHUNK = 64;
+__global__ __launch_bounds__(256) void rs_scan_chunk_sum(const uint32_t* __restrict__ hist, uint32_t T, uint32_t* __restrict__ csum) {
+  const uint32_t t0 = blockIdx.x * SB_CHUNK, t1 = t0 + SB_CHUNK < T ? t0 + SB_CHUNK : T;
+  uint32_t acc = 0;
+  for (uint32_t t = t0; t < t1; t++) acc += hist[(size_t)t * 256 + threadIdx.x];
+  csum[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void rs_scan_chunk_mid(uint32_t* __restrict__ csum, uint32_t nch, uint32_t* __restrict__ bintot) {
+  uint32_t carry = 0;
+  for (uint32_t c = 0; c < nch; c++) { const uint32_t v = csum[(size_t)c * 256 + threadIdx.x]; csum[(size_t)c * 256 + threadIdx.x] = carry; carry += v; }
+  bintot[threadIdx.x] = carry;
+}
+__global__ __launch_bounds__(256) void rs_scan_chunk_apply(uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ csum) {
+  const uint32_t t0 = blockIdx.x * SB_CHUNK, t1 = t0 + SB_CHUNK < T ? t0 + SB_CHUNK : T;
+  uint32_t carry = csum[(size_t)blockIdx.x * 256 + threadIdx.x];
+  for (uint32_t t = t0; t < t1; t++) { const uint32_t v = hist[(size_t)t * 256 + threadIdx.x]; hist[(size_t)t * 256 + threadIdx.x] = carry; carry += v; }
 }
 
 __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
@@ -143,12 +175,12 @@ __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
   return peers;
 }
 
-template <typename K, bool GEN>
+template <typename K, bool GEN, bool NOVAL>
 __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                   K* __restrict__ kout, uint32_t* __restrict__ vout, SegGeom sg, GenSrc gs, int shift,
                                                   const uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ bintot) {
   __shared__ K skey[RS_TILE + 2];
-  __shared__ uint32_t sval[RS_TILE];
+  __shared__ uint32_t sval[NOVAL ? 1 : RS_TILE];
   __shared__ uint32_t wcnt[4][256];
   __shared__ uint32_t goff[256];
   __shared__ uint32_t sm[4];
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
       const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
       const bool ok = loc < nvalid;
       k[s] = ok ? kin[base + loc] : (K)~(K)0;
-      v[s] = ok ? vin[base + loc] : 0u;
+      v[s] = (ok && !NOVAL) ? vin[base + loc] : 0u;
     }
   }
   __syncthreads();
@@ -202,7 +234,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
     uint32_t tot2;
     const uint32_t binbase = block_excl_sum<256>(bintot[(size_t)t.seg * 256 + tid], sm, tot2);
     wcnt[0][tid] = ex; wcnt[1][tid] = ex + c0; wcnt[2][tid] = ex + c0 + c1; wcnt[3][tid] = ex + c0 + c1 + c2;
-    goff[tid] = t.seg * sg.stride + binbase + hist[(size_t)tid * T + tile] - ex;
+    goff[tid] = t.seg * sg.stride + binbase + hist[(size_t)tile * 256 + tid] - ex;
   }
   __syncthreads();
 #pragma unroll
@@ -210,7 +242,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
     const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
     const uint32_t p = wcnt[w][d] + rk[s];
     skey[p] = k[s];
-    sval[p] = v[s];
+    if (!NOVAL) sval[p] = v[s];
   }
   __syncthreads();
 #pragma unroll 4
@@ -220,130 +252,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
       const K kk = skey[j];
       const uint32_t dst = goff[(uint32_t)(kk >> shift) & 255u] + j;
       kout[dst] = kk;
-      vout[dst] = sval[j];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Single-pass-per-digit variant ("onesweep"): digit histograms of ALL passes are taken in one read of the
-// keys (digit counts do not depend on the order), and each scatter pass gets its tile offsets by decoupled
-// look-back over per-tile status words instead of a separate histogram + scan pass:
-//   status[tile][digit] = flag(2) | count(30): 1 = this tile's count, 2 = inclusive prefix up to this tile.
-// Tiles take their index from an atomic ticket, so every lower-numbered tile is already resident when a
-// tile waits on it.  Status words are single 4-byte agent-scope (sc1) atomics: value and flag travel together
-// (MI355X: per-XCD L2s are not coherent, see cdna_hip_programming.md Guideline 16 R2).  Spins are bounded.
-// ------------------------------------------------------------------------------------------
-template <typename K>
-__global__ __launch_bounds__(256) void rs_ghist(const K* __restrict__ keys, uint32_t n, int lo_bit, int npasses, uint32_t* __restrict__ ghist, uint32_t T) {
-  __shared__ uint32_t h[8][256];
-  for (int i = threadIdx.x; i < 8 * 256; i += 256) (&h[0][0])[i] = 0;
-  __syncthreads();
-  for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
-    const uint64_t base = (uint64_t)tile * RS_TILE;
-#pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-      const uint64_t idx = base + (uint32_t)it * 256 + threadIdx.x;
-      if (idx < n) {
-        const K k = keys[idx];
-        for (int p = 0; p < npasses; p++) atomicAdd(&h[p][(uint32_t)(k >> (lo_bit + 8 * p)) & 255u], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  for (int p = 0; p < npasses; p++) { const uint32_t v = h[p][threadIdx.x]; if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], v); }
-}
-__global__ __launch_bounds__(256) void rs_gscan(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ gbase) {
-  __shared__ uint32_t sm[4];
-  uint32_t tot;
-  gbase[blockIdx.x * 256 + threadIdx.x] = block_excl_sum<256>(ghist[blockIdx.x * 256 + threadIdx.x], sm, tot);
-}
-
-constexpr uint32_t OS_MASK = (1u << 30) - 1u;
-template <typename K>
-__global__ __launch_bounds__(256) void rs_onesweep(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                   K* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
-                                                   const uint32_t* __restrict__ gbase, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                   uint32_t* __restrict__ errflag) {
-  __shared__ K skey[RS_TILE];
-  __shared__ uint32_t sval[RS_TILE];
-  __shared__ uint32_t wcnt[4][256];
-  __shared__ uint32_t goff[256];
-  __shared__ uint32_t sm[4];
-  __shared__ uint32_t tile_s;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  if (tid == 0) tile_s = atomicAdd(ticket, 1u);
-  for (int i = tid; i < 1024; i += 256) (&wcnt[0][0])[i] = 0;
-  __syncthreads();
-  const uint32_t tile = tile_s;
-  const uint64_t base = (uint64_t)tile * RS_TILE;
-  const uint32_t nvalid = (uint32_t)((uint64_t)n - base < RS_TILE ? (uint64_t)n - base : RS_TILE);
-  K k[16];
-  uint32_t v[16];
-  uint32_t rk[16];
-#pragma unroll
-  for (int s = 0; s < 16; s++) {
-    const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
-    const bool ok = loc < nvalid;
-    k[s] = ok ? kin[base + loc] : (K)~(K)0;
-    v[s] = ok ? vin[base + loc] : 0u;
-  }
-  const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int s = 0; s < 16; s++) {
-    const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
-    const uint64_t peers = match_any8(d);
-    const uint32_t prior = wcnt[w][d];
-    const uint32_t r = (uint32_t)__popcll(peers & lt);
-    rk[s] = prior + r;
-    __builtin_amdgcn_wave_barrier();
-    if (r == 0) wcnt[w][d] = prior + (uint32_t)__popcll(peers);
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-  {
-    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-    // the padding elements of the last tile carry digit 255: they must not be counted
-    const uint32_t pad = (tid == 255) ? RS_TILE - nvalid : 0u;
-    const uint32_t mine = c0 + c1 + c2 + c3 - pad;
-    uint32_t total;
-    const uint32_t ex = block_excl_sum<256>(c0 + c1 + c2 + c3, sm, total);
-    uint32_t* st = status + (size_t)tile * 256 + tid;
-    uint32_t prefix = 0;
-    if (tile == 0) __hip_atomic_store(st, (2u << 30) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else {
-      __hip_atomic_store(st, (1u << 30) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t t = tile - 1, spins = 0;
-      for (;;) {
-        const uint32_t sv = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t f = sv >> 30;
-        if (f == 2u) { prefix += sv & OS_MASK; break; }
-        if (f == 1u) { prefix += sv & OS_MASK; t--; spins = 0; continue; }
-        if (++spins > (1u << 22)) { *errflag = 1u; break; }     // cannot happen: the predecessor tile is resident
-        __builtin_amdgcn_s_sleep(2);
-      }
-      __hip_atomic_store(st, (2u << 30) | ((prefix + mine) & OS_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    wcnt[0][tid] = ex; wcnt[1][tid] = ex + c0; wcnt[2][tid] = ex + c0 + c1; wcnt[3][tid] = ex + c0 + c1 + c2;
-    goff[tid] = gbase[tid] + prefix - ex;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < 16; s++) {
-    const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
-    const uint32_t p = wcnt[w][d] + rk[s];
-    skey[p] = k[s];
-    sval[p] = v[s];
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int it = 0; it < 16; it++) {
-    const uint32_t j = (uint32_t)it * 256u + tid;
-    if (j < nvalid) {
-      const K kk = skey[j];
-      const uint32_t dst = goff[(uint32_t)(kk >> shift) & 255u] + j;
-      kout[dst] = kk;
-      vout[dst] = sval[j];
+      if (!NOVAL) vout[dst] = sval[j];
     }
   }
 }
@@ -392,16 +301,16 @@ __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint3
 }
 
 // per 4096-tile: #surviving elements, #surviving group heads, (last new-head index)+1
-__global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ key, uint32_t A, uint32_t* __restrict__ tile_cnt, uint32_t T) {
+__global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ key, uint32_t A, uint32_t* __restrict__ tile_cnt, uint32_t T, int gshift) {
   __shared__ uint32_t sm[4];
   const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
   uint32_t surv = 0, heads = 0, last = 0;
   for (int it = 0; it < 16; it++) {
     const uint64_t a = base + (uint32_t)it * 256 + threadIdx.x;
     if (a < A) {
-      const uint64_t k = key[a];
-      const bool nh = a == 0 || key[a - 1] != k;
-      const bool nx = a + 1 == A || key[a + 1] != k;
+      const uint64_t k = key[a] >> gshift;            // packed round-1 records: the low bits are the position
+      const bool nh = a == 0 || (key[a - 1] >> gshift) != k;
+      const bool nx = a + 1 == A || (key[a + 1] >> gshift) != k;
       const bool single = nh && nx;
       surv += !single;
       heads += nh && !single;
@@ -450,17 +359,36 @@ __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ ti
 // regroup: new ranks -> R (scattered 4-byte stores), singletons -> SA, survivors compacted into the next
 // active arrays.  Fully lane-striped: the per-element prefix quantities come from 4096-bit masks
 // (wave ballots) + a 64-word scan, so every global access of a wave touches consecutive addresses.
-template <bool FIRST>      // FIRST: round 1 - slot a is sorted position a, and there is no previous grouping
+// Two-sweep rank scatter (round 1, `halves` = 2): the scattered 4-byte stores into a block's 3.6 MB rank region do not
+// survive in a 4 MiB L2 next to the streamed arrays (PMC: ~43 B written per store).  Each XCD therefore walks the tiles
+// of one block twice, storing first the ranks of the lower half of the block's text positions, then the upper half
+// (1.8 MB of destination per sweep); everything else is written by the first sweep only.  Blocks are dealt to the XCDs
+// round-robin (workgroup 8j+x -> XCD x), HALF_SLOTS tile slots per (block, sweep).
+struct HalfMap { uint32_t halves, slots, stride; };
+template <bool FIRST, bool PACKED>      // FIRST: round 1 - slot a is sorted position a, and there is no previous grouping
 __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                  const uint32_t* __restrict__ pos, uint32_t A, Geom g,
                                                  const uint32_t* __restrict__ tile_cnt, uint32_t T,
                                                  uint32_t* __restrict__ R, uint32_t* __restrict__ SA,
-                                                 uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord) {
+                                                 uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord, HalfMap hm_) {
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
-  const uint32_t tile = xcd_tile(blockIdx.x, T);
+  uint32_t tile, half = 0;
+  if (hm_.halves <= 1) tile = xcd_tile(blockIdx.x, T);
+  else {
+    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = 2u * hm_.slots;
+    const uint32_t bi = j / per, r = j - bi * per, blk = x + 8u * bi;
+    half = r / hm_.slots;
+    if (blk >= g.nb) return;
+    const uint32_t ft = (uint32_t)(((uint64_t)blk * hm_.stride + RS_TILE - 1) / RS_TILE);
+    uint32_t fe = (uint32_t)(((uint64_t)(blk + 1) * hm_.stride + RS_TILE - 1) / RS_TILE);
+    if (fe > T || blk + 1 == g.nb) fe = T;
+    tile = ft + (r - half * hm_.slots);
+    if (tile >= fe) return;
+  }
   if (tile >= T) return;
+  const uint32_t hsplit = hm_.stride >> 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint64_t base = (uint64_t)tile * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
@@ -474,18 +402,19 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
     sk[RS_TILE + 1] = base + RS_TILE < A ? key[base + RS_TILE] : ~0ull;
   }
   __syncthreads();
+  constexpr int GS = PACKED ? PK_SHIFT : 0;      // packed records: the group key sits above the position bits
 #pragma unroll 4
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
     const uint64_t a = base + e;
     const bool ok = e < nvalid;
-    const uint64_t k = sk[e + 1];
-    const bool nh = ok && (a == 0 || sk[e] != k);
-    const bool nx = a + 1 == A || sk[e + 2] != k;
+    const uint64_t k = sk[e + 1] >> GS;
+    const bool nh = ok && (a == 0 || (sk[e] >> GS) != k);
+    const bool nx = a + 1 == A || (sk[e + 2] >> GS) != k;
     const uint64_t mnh = __ballot(nh), msg = __ballot(nh && nx);
     if (lane == 0) { m_nh[it * 4 + w] = mnh; m_sg[it * 4 + w] = msg; }
     if (!FIRST) {
-      const bool oh = ok && (a == 0 || (sk[e] >> 20) != (k >> 20));      // head of a group of the previous round
+      const bool oh = ok && (a == 0 || (sk[e] >> 20) != (sk[e + 1] >> 20));      // head of a group of the previous round
       const uint64_t moh = __ballot(oh);
       if (lane == 0) m_oh[it * 4 + w] = moh;
     }
@@ -524,10 +453,12 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
         head_a = carry - 1u;
         if (!FIRST) keeps_rank = head_a == 0 || (key[head_a] >> 20) != (key[head_a - 1] >> 20);
       }
-      const uint32_t p = FIRST ? (uint32_t)a : __builtin_nontemporal_load(pos + a), vv = __builtin_nontemporal_load(val + a);
+      const uint32_t p = FIRST ? (uint32_t)a : __builtin_nontemporal_load(pos + a);
+      const uint32_t vv = PACKED ? ((uint32_t)sk[e + 1] & PK_POS_MASK) : __builtin_nontemporal_load(val + a);
       const uint32_t blk = p / g.stride;
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
-      if (!keeps_rank) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
+      if (!keeps_rank && (hm_.halves <= 1 || (uint32_t)(vv >= hsplit) == half)) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
+      if (half) continue;
       if ((ms >> lane) & 1ull) __builtin_nontemporal_store(vv, SA + p);
       else {
         const uint32_t so = sbase + wp_s[wi] + (uint32_t)__popcll(~ms & lt);
@@ -708,6 +639,122 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     }
   }
 }
+// LDS radix version of the tile sorter.  Every slot of the window gets a 32-bit composite (head slot of its group << 20 |
+// 20-bit rank key); slots that are not owned carry (own slot << 20).  A stable LSD radix sort of the whole window on that
+// composite (4 passes of 8 bits, wave64 match-any ranking, one LDS staging array) is then a permutation INSIDE every owned
+// group: exactly h slots carry a composite below (h << 20), so the members of the group headed at h land on [h, h + size).
+// The cost does not depend on the group sizes (the counting / bitonic version above degrades with them).
+__global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
+                                                           uint8_t* __restrict__ dflag) {
+  __shared__ uint64_t se[TS_WIN];                // (composite << 32) | suffix: staging of a pass
+  __shared__ uint64_t hm[64];
+  __shared__ int32_t wlast[64], wnext[64];
+  __shared__ uint32_t wcnt[4][256];
+  __shared__ uint32_t sm[4];
+  uint32_t* gk = (uint32_t*)se;                  // group ordinals of the window slots (only until the heads are known)
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const uint64_t wb = (uint64_t)blockIdx.x * TS_NOM;
+  const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
+  const uint32_t L = (uint32_t)(we - wb);
+  // slot of (wave w, step s, lane): w * 1024 + s * 64 + lane -- array order = (w, s, lane) order, which the stable ranking needs
+  uint32_t rk20[16], go[16];
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+    const uint64_t k = x < L ? key[wb + x] : ~0ull;
+    go[s] = (uint32_t)(k >> 20); rk20[s] = (uint32_t)k & 0xFFFFFu;
+    gk[x] = go[s];
+  }
+  const uint32_t gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+    const bool head = x < L && (wb + x == 0 || gk[x] != (x ? gk[x - 1] : gprev));
+    const uint64_t m = __ballot(head);
+    if (lane == 0) hm[w * 16 + s] = m;
+  }
+  __syncthreads();
+  if (w == 0) {      // per mask word: last head strictly before the word, first head strictly after it
+    const uint64_t m = hm[lane];
+    const int lastin = m ? lane * 64 + 63 - (int)__builtin_clzll(m) : -1;
+    const int firstin = m ? lane * 64 + (int)__builtin_ctzll(m) : (int)TS_WIN + 1;
+    int il = wave_incl_max(lastin);
+    int el = __shfl_up(il, 1, 64); if (lane == 0) el = -1;
+    int neg = -firstin;
+    int rv = __shfl(neg, 63 - lane, 64);
+    int ir = wave_incl_max(rv);
+    int er = __shfl_up(ir, 1, 64); if (lane == 0) er = -((int)TS_WIN + 1);
+    const int en = -__shfl(er, 63 - lane, 64);
+    wlast[lane] = el; wnext[lane] = en;
+  }
+  __syncthreads();
+  uint32_t comp[16], pv[16];
+  uint32_t ownm = 0;
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+    const int wi = w * 16 + s;
+    const uint64_t m = hm[wi];
+    const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const uint64_t gt = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    const int hx = (m & le) ? wi * 64 + 63 - (int)__builtin_clzll(m & le) : wlast[wi];            // head slot of my group (-1: before the window)
+    int nx = (m & gt) ? wi * 64 + (int)__builtin_ctzll(m & gt) : wnext[wi];                        // next head after me
+    if (nx > (int)L) nx = (we == A) ? (int)L : (int)TS_WIN + 1;                                    // the array end closes the last group
+    const bool owned = x < L && hx >= 0 && nx <= (int)L && (uint32_t)(nx - hx) <= TS_MAXGRP && (uint32_t)hx < TS_NOM;
+    if (owned && dflag) dflag[wb + x] = 0;
+    ownm |= owned ? 1u << s : 0u;
+    comp[s] = owned ? (((uint32_t)hx << 20) | rk20[s]) : (x << 20);
+    pv[s] = owned ? val[wb + x] : 0u;
+  }
+  if (!__syncthreads_or((int)ownm)) return;      // also: gk (aliasing se) is dead from here
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+  for (int shift = 0; shift < 32; shift += 8) {
+    for (int i = tid; i < 1024; i += 256) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t rk[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t d = (comp[s] >> shift) & 255u;
+      const uint64_t peers = match_any8(d);
+      const uint32_t prior = wcnt[w][d];
+      const uint32_t r = (uint32_t)__popcll(peers & lt);
+      rk[s] = prior + r;
+      __builtin_amdgcn_wave_barrier();
+      if (r == 0) wcnt[w][d] = prior + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+      const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+      uint32_t total;
+      const uint32_t ex = block_excl_sum<256>(c0 + c1 + c2 + c3, sm, total);
+      wcnt[0][tid] = ex; wcnt[1][tid] = ex + c0; wcnt[2][tid] = ex + c0 + c1; wcnt[3][tid] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t d = (comp[s] >> shift) & 255u;
+      se[wcnt[w][d] + rk[s]] = ((uint64_t)comp[s] << 32) | pv[s];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint64_t e = se[(uint32_t)w * 1024u + (uint32_t)s * 64u + lane];
+      comp[s] = (uint32_t)(e >> 32); pv[s] = (uint32_t)e;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    if ((ownm >> s) & 1u) {
+      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+      key[wb + x] = ((uint64_t)go[s] << 20) | (comp[s] & 0xFFFFFu);
+      val[wb + x] = pv[s];
+    }
+  }
+}
 // single workgroup: exclusive scan of n counters in place, total -> *total
 __global__ __launch_bounds__(1024) void scan_u32_single(uint32_t* __restrict__ arr, uint32_t n, uint32_t* __restrict__ total, uint32_t* __restrict__ host_total) {
   __shared__ uint32_t sm[16];
@@ -831,7 +878,7 @@ size_t BwtWork::bytes_needed(size_t cap) {
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
   add(cap * 8); add(cap * 8); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4);  // key x2, val x2, pos x2, gord
   add(cap * 4); add(cap * 4);           // R, SA
-  add(256 * T * 4); add(256 * segs_for(cap) * 4); add(3 * T * 4); add(64); add(16 * 256 * 4);
+  add(hist_words(T) * 4); add(256 * segs_for(cap) * 4); add(3 * T * 4); add(64); add(16 * 256 * 4);
   return b + 4096;
 }
 int BwtWork::carve(Arena& a, size_t cap_) {
@@ -843,7 +890,7 @@ int BwtWork::carve(Arena& a, size_t cap_) {
   pos[0] = a.take<uint32_t>(cap); pos[1] = a.take<uint32_t>(cap);
   gord = a.take<uint32_t>(cap);
   R = a.take<uint32_t>(cap); SA = a.take<uint32_t>(cap);
-  hist = a.take<uint32_t>(256 * T); bintot = a.take<uint32_t>(256 * (size_t)bintot_segs);
+  hist = a.take<uint32_t>(hist_words(T)); bintot = a.take<uint32_t>(256 * (size_t)bintot_segs);
   tile_cnt = a.take<uint32_t>(3 * T); counters = a.take<uint32_t>(16);
   ghist = a.take<uint32_t>(16 * 256);
   if (!counters || !ghist) return CJS_E_OUT_OF_MEMORY;
@@ -875,46 +922,36 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
 
 template <typename K>
 static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
-                        LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr) {
+                        LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr, bool noval = false) {
   const uint32_t T1 = (n + RS_TILE - 1) / RS_TILE;
   const SegGeom sg = seg ? *seg : SegGeom{1u, n, n, T1};
   const uint32_t T = sg.nseg * sg.tps;
   if (T > w.hist_tiles || sg.nseg > w.bintot_segs) return CJS_E_INVALID_ARG;
   K* kk[2] = {k0, k1}; uint32_t* vv[2] = {v0, v1};
-  const int npasses = (hi_bit - lo_bit + 7) / 8;
-  // Measured on MI355X (100 MB, level 9): the look-back passes are correct but slower than the three-kernel
-  // passes (BWT 26.4 ms vs 23.2 ms: one lane per digit walks predecessor tiles serially, ~1 us per sc1 poll),
-  // so they stay opt-in until the look-back is widened to a wave per window.
-  static const bool classic = getenv("CJS_ONESWEEP") == nullptr;
-  if (!classic && !seg && !gen && w.ghist && npasses >= 1 && npasses <= 8 && n < (1u << 30)) {
-    // one histogram read for all digits + look-back scatter passes
-    uint32_t* gbase = w.ghist + 8 * 256;
-    uint32_t* ticket = w.counters + 8; uint32_t* errflag = w.counters + 9;
-    CJS_HIP_TRY(hipMemsetAsync(w.ghist, 0, 8 * 256 * 4, s));
-    hipLaunchKernelGGL(rs_ghist<K>, dim3(T < 2048u ? T : 2048u), dim3(256), 0, s, kk[cur], n, lo_bit, npasses, w.ghist, T);
-    hipLaunchKernelGGL(rs_gscan, dim3(npasses), dim3(256), 0, s, w.ghist, gbase);
-    for (int p = 0; p < npasses; p++) {
-      CJS_HIP_TRY(hipMemsetAsync(w.hist, 0, (size_t)T * 256 * 4, s));
-      CJS_HIP_TRY(hipMemsetAsync(ticket, 0, 4, s));
-      if (lt) lt->begin(s, n);
-      hipLaunchKernelGGL(rs_onesweep<K>, dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], n, lo_bit + 8 * p,
-                         gbase + p * 256, w.hist, ticket, errflag);
-      if (lt) lt->end(s);
-      cur = 1 - cur;
-    }
-    CJS_HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  const GenSrc g0{nullptr, 0, 0};
+  const GenSrc g0{nullptr, 0, 0, 0};
   for (int shift = lo_bit; shift < hi_bit; shift += 8) {
     const bool first_gen = gen && shift == lo_bit;        // the first pass makes its keys from the block bytes
     if (first_gen) hipLaunchKernelGGL((rs_hist<K, true>), dim3(T), dim3(256), 0, s, kk[cur], sg, *gen, shift, w.hist, T);
     else hipLaunchKernelGGL((rs_hist<K, false>), dim3(T), dim3(256), 0, s, kk[cur], sg, g0, shift, w.hist, T);
-    if (sg.tps <= 512) hipLaunchKernelGGL(rs_scan_bins<256>, dim3(256, sg.nseg), dim3(256), 0, s, w.hist, T, sg.tps, w.bintot);
-    else hipLaunchKernelGGL(rs_scan_bins<1024>, dim3(256, sg.nseg), dim3(1024), 0, s, w.hist, T, sg.tps, w.bintot);
+    if (sg.tps <= 4 * SB_CHUNK) hipLaunchKernelGGL(rs_scan_bins, dim3(sg.nseg), dim3(256), 0, s, w.hist, sg.tps, w.bintot);
+    else {                                    // one long segment (nseg > 1 with long segments: still correct, one launch per segment)
+      for (uint32_t sgi = 0; sgi < sg.nseg; sgi++) {
+        uint32_t* hseg = w.hist + (size_t)sgi * sg.tps * 256;
+        const uint32_t nch = (sg.tps + SB_CHUNK - 1) / SB_CHUNK;
+        uint32_t* csum = w.hist + (size_t)w.hist_tiles * 256;          // behind the per-tile rows (BwtWork::hist_words)
+        hipLaunchKernelGGL(rs_scan_chunk_sum, dim3(nch), dim3(256), 0, s, hseg, sg.tps, csum);
+        hipLaunchKernelGGL(rs_scan_chunk_mid, dim3(1), dim3(256), 0, s, csum, nch, w.bintot + (size_t)sgi * 256);
+        hipLaunchKernelGGL(rs_scan_chunk_apply, dim3(nch), dim3(256), 0, s, hseg, sg.tps, csum);
+      }
+    }
     if (lt) lt->begin(s, n);
-    if (first_gen) hipLaunchKernelGGL((rs_scatter<K, true>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, *gen, shift, w.hist, T, w.bintot);
-    else hipLaunchKernelGGL((rs_scatter<K, false>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, g0, shift, w.hist, T, w.bintot);
+    if (noval) {
+      if (first_gen) hipLaunchKernelGGL((rs_scatter<K, true, true>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, *gen, shift, w.hist, T, w.bintot);
+      else hipLaunchKernelGGL((rs_scatter<K, false, true>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, g0, shift, w.hist, T, w.bintot);
+    } else {
+      if (first_gen) hipLaunchKernelGGL((rs_scatter<K, true, false>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, *gen, shift, w.hist, T, w.bintot);
+      else hipLaunchKernelGGL((rs_scatter<K, false, false>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, g0, shift, w.hist, T, w.bintot);
+    }
     if (lt) lt->end(s);
     cur = 1 - cur;
   }
@@ -930,7 +967,9 @@ int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
 template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, int, int);
 
 static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag) {
-  hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
+  static const bool radix = getenv("CJS_TILE_SORT") != nullptr && !strcmp(getenv("CJS_TILE_SORT"), "radix");
+  if (radix) hipLaunchKernelGGL(bwt_tile_sort_radix, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
+  else hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
 }
 // One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.
 // Works in place on (key[c], val[c]); only the whole-array fallback flips c.
@@ -990,31 +1029,42 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   const int blk_bits = bits_for(nb - 1);
   int nsym = segmented ? 7 : (64 - blk_bits) / sym_bits;
   if (nsym > 7) nsym = 7;
+  // packed round-1 records (5 bytes + position in one u64, no value array): cyclic, segmented sorts only
+  static const bool env_packed = getenv("CJS_R1_PACKED") != nullptr && atoi(getenv("CJS_R1_PACKED")) != 0;
+  static const int env_halves = getenv("CJS_APPLY_HALVES") ? atoi(getenv("CJS_APPLY_HALVES")) : 0;
+  const bool packed = env_packed && segmented && cyclic;
+  if (packed) nsym = 5;
   const SegGeom sg{nb, stride, n_last, tps};
-  const GenSrc gen{d_T, cyclic ? 1 : 0, nsym};
+  const GenSrc gen{d_T, cyclic ? 1 : 0, nsym, packed ? 1 : 0};
   if (!segmented) hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0]);
   uint32_t A = M, h = (uint32_t)nsym, rounds = 0;
   w.no_large_groups = false;
   int bits = nsym * sym_bits + (segmented ? 0 : blk_bits);
   for (;;) {
     if (rounds == 0) {
-      if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
+      if (packed) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
+      else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
     } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
-    hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T);
+    hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
-    if (rounds == 0) hipLaunchKernelGGL(bwt_apply<true>, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                                        w.val[1 - c], w.pos[1 - pc], w.gord);
-    else hipLaunchKernelGGL(bwt_apply<false>, dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                            w.val[1 - c], w.pos[1 - pc], w.gord);
-    static const bool onesweep = getenv("CJS_ONESWEEP") != nullptr;
-    if (onesweep) CJS_HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters, 40, hipMemcpyDeviceToHost, s));      // (its look-back error flag; the round counters arrive through the pinned mirror)
-    else w.h_counters[9] = 0;
+    if (rounds == 0) {
+      HalfMap hm{1u, 0u, stride};
+      uint32_t grid = xcd_grid(T);
+      if (env_halves >= 2 && nb >= 8) {        // two destination sweeps per block (see bwt_apply)
+        hm.halves = 2; hm.slots = (stride + RS_TILE - 1) / RS_TILE + 1;
+        grid = 8u * ((nb + 7u) / 8u) * 2u * hm.slots;
+      }
+      if (packed) hipLaunchKernelGGL((bwt_apply<true, true>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+                                     w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+      else hipLaunchKernelGGL((bwt_apply<true, false>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+                              w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+    } else hipLaunchKernelGGL((bwt_apply<false, false>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride});
     CJS_HIP_TRY(hipStreamSynchronize(s));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
-    if (w.h_counters[9]) { fprintf(stderr, "[cjs_hip] radix look-back timed out\n"); return CJS_E_HIP; }
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt] round %u h=%u A=%u bits=%d -> A'=%u groups=%u\n", rounds, h, A, bits, A2, NG);
     c = 1 - c; pc = 1 - pc;
     A = A2;

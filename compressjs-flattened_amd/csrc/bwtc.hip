@@ -19,7 +19,7 @@
 
 namespace cjs {
 int select_device(const cjs_opts* opts);
-int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32_t nb, const uint32_t* lens, const uint32_t* pidx, uint8_t* d_out);
+int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t max_len, uint32_t nb, const uint32_t* lens, const uint32_t* pidx, uint8_t* d_out);
 }
 using namespace cjs;
 
@@ -579,199 +579,289 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
 // Range decoding and the adaptive model are one serial chain over the whole file (every decoded symbol feeds the
 // model that decodes the next one), so that part runs on one host thread; the inverse BWT of all blocks
 // (BWT.unbwtransform, n dependent gathers per block in the reference) runs on the GPU (decode.hip).
+//
+// The host side keeps the stream format's arithmetic (it IS the format) but not the reference's data structures: the
+// adaptive models are flat per-symbol counters laid out in CODING ORDER with 16-entry bucket sums, searched linearly
+// (2 short scans per symbol), instead of the reference's implicit binary tree walked and updated level by level.
 namespace {
 
-struct HostDecoder {                                    // RangeCoder decode side (:159-238)
-  const uint8_t* in; size_t n, pos;
-  uint32_t low = 0, range = 0, help = 0; int32_t buffer = 0;
-  int32_t read_byte() { return pos < n ? (int32_t)in[pos++] : -1; }
-  void start() { buffer = read_byte(); low = (uint32_t)buffer >> 1; range = 1u << 7; }          // decodeStart(skipInitialRead)
-  inline void normalize() {
-    while (range <= 0x00800000u) {
-      low = (low << 8) | (((uint32_t)buffer << 7) & 0xFF);
-      buffer = read_byte();
-      low |= (uint32_t)buffer >> 1;
-      range <<= 8;
+// Byte source + the decoder half of the carry-less range coder (interval state as RangeCoder's decode side, :159-238).
+class RangeDecoder {
+ public:
+  RangeDecoder(const uint8_t* p, size_t n, size_t at) : in_(p), n_(n), pos_(at) {}
+  void begin() { last_ = next_byte(); low_ = (uint32_t)last_ >> 1; range_ = 1u << 7; }           // decodeStart(skipInitialRead)
+  // cumulative-frequency target under total `tot` / under 2^sh; the matching commit() must follow
+  uint32_t target(uint32_t tot) { refill(); unit_ = range_ / tot; const uint32_t t = unit_ ? low_ / unit_ : 0; return t >= tot ? tot - 1 : t; }
+  uint32_t target_pow2(int sh) { refill(); unit_ = range_ >> sh; const uint32_t t = unit_ ? low_ / unit_ : 0; return (t >> sh) ? (1u << sh) - 1 : t; }
+  void commit(uint32_t sy, uint32_t lt, uint32_t tot) { const uint32_t base = unit_ * lt; low_ -= base; if (lt + sy < tot) range_ = unit_ * sy; else range_ -= base; }
+  uint32_t bit() { const uint32_t t = target_pow2(1); commit(1, t, 2); return t; }
+  uint32_t bits(int k) { uint32_t r = 0; while (k-- > 0) r = (r << 1) | bit(); return r; }         // NoModel (:1274-1287)
+  uint32_t log_distance(int block_size) {                                                           // LogDistanceModel.decode (:1254-1261)
+    const int lgbits = fls32((uint32_t)(1 + fls32((uint32_t)block_size - 1)) - 1);
+    const uint32_t lg = bits(lgbits);
+    return lg < 2 ? lg : (1u << (lg - 1)) + bits((int)lg - 1);
+  }
+  bool exhausted() const { return past_end_ > 8; }       // a well-formed stream never reads more than a few bytes past its end
+  size_t consumed() const { return pos_; }
+ private:
+  int32_t next_byte() { if (pos_ < n_) return in_[pos_++]; past_end_++; return -1; }
+  void refill() {
+    while (range_ <= 0x00800000u) {
+      low_ = (low_ << 8) | (((uint32_t)last_ << 7) & 0xFF);
+      last_ = next_byte();
+      low_ |= (uint32_t)last_ >> 1;
+      range_ <<= 8;
     }
   }
-  inline uint32_t cul_freq(uint32_t tot) { normalize(); help = range / tot; const uint32_t t = help ? low / help : 0; return t >= tot ? tot - 1 : t; }
-  inline uint32_t cul_shift(int sh) { normalize(); help = range >> sh; const uint32_t t = help ? low / help : 0; return (t >> sh) ? (1u << sh) - 1 : t; }
-  inline void update(uint32_t sy, uint32_t lt, uint32_t tot) { const uint32_t tmp = help * lt; low -= tmp; if (lt + sy < tot) range = help * sy; else range -= tmp; }
-  uint32_t bit() { const uint32_t t = cul_shift(1); update(1, t, 2); return t; }
-  bool overrun() const { return pos >= n + 8; }
+  const uint8_t* in_; size_t n_, pos_;
+  uint32_t low_ = 0, range_ = 0, unit_ = 0, past_end_ = 0; int32_t last_ = 0;
 };
-uint32_t nomodel_dec(HostDecoder& d, int bits) { uint32_t r = 0; for (int i = bits - 1; i >= 0; i--) { r <<= 1; if (d.bit()) r++; } return r; }
-uint32_t logdist_dec(HostDecoder& d, int block_size) {                                          // :1254-1261
-  const int lgbits = fls32((uint32_t)(1 + fls32((uint32_t)block_size - 1)) - 1);
-  const uint32_t lg = nomodel_dec(d, lgbits);
-  if (lg < 2) return lg;
-  return (1u << (lg - 1)) + nomodel_dec(d, (int)lg - 1);
-}
 
-struct FenDec {                                         // FenwickModel decode side (:1572-1661)
-  HostDecoder& d; int num_syms; std::vector<uint32_t> tree;
-  FenDec(HostDecoder& dd, int size) : d(dd), num_syms(size + 1), tree((size_t)(size + 1) * 2, 0) {
-    int i; for (i = 0; i < size; i++) tree[num_syms + i] = 1u;
-    tree[num_syms + i] = 0x100u << 16; sum();
+// FenwickModel, decode side (:1572-1661), as flat counters.  The reference keeps (count << 16 | unseen marker) in an
+// implicit binary tree over num_syms leaves (num_syms not a power of two): the cumulative order of the symbols is the
+// left-to-right order of the leaves = the deepest level first.  Here: slot o of the coding order holds the count and the
+// unseen marker of symbol sym_[o]; 16-slot bucket sums make the cumulative search two short linear scans.
+class RankModelDecoder {
+ public:
+  RankModelDecoder(RangeDecoder& d, int size) : d_(d), n_(size + 1) {
+    int deep = 1; while (deep * 2 <= 2 * n_ - 1) deep *= 2;          // first heap position of the deepest level
+    int o = 0;
+    for (int leaf = deep; leaf < 2 * n_; leaf++) sym_[o++] = (uint16_t)(leaf - n_);
+    for (int leaf = n_; leaf < deep; leaf++) sym_[o++] = (uint16_t)(leaf - n_);
+    for (o = 0; o < n_; o++) { const bool esc = sym_[o] == n_ - 1; cnt_[o] = esc ? 0x100u : 0u; unseen_[o] = esc ? 0 : 1; if (esc) esc_slot_ = o; }
+    resum();
   }
-  void sum() { for (int i = num_syms - 1; i > 0; i--) tree[i] = tree[2 * i] + tree[2 * i + 1]; }
-  void rescale() {
-    int i; bool no_escape = true; uint32_t prob;
-    for (i = 0; i < num_syms - 1; i++) {
-      prob = tree[num_syms + i];
-      if (prob & 0xFFFFu) { no_escape = false; continue; }
-      prob = (prob & 0xFFFEFFFEu) >> 1;
-      if (prob == 0) { prob = 1u; no_escape = false; }
-      tree[num_syms + i] = prob;
+  int decode() {                                                    // -1: corrupt stream
+    int o = take(cnt_, bcnt_, cnt_total_);
+    if (o < 0) return -1;
+    if (o == esc_slot_) {
+      // the escape symbol: the novel symbol follows in the distribution of the unseen markers (:1590-1600); once the
+      // last unseen symbol is about to go the escape symbol disappears with it (:1648)
+      cnt_[o] += 0x100u; bcnt_[o >> 4] += 0x100u; cnt_total_ += 0x100u;
+      if (unseen_total_ == 1) { cnt_total_ -= cnt_[o]; bcnt_[o >> 4] -= cnt_[o]; cnt_[o] = 0; }
+      if (cnt_total_ >= 0xFF00u) halve();
+      uint32_t ut = unseen_total_;
+      if (ut == 0) return -1;
+      o = take_unseen(ut);
+      if (o < 0) return -1;
+      unseen_[o] = 0; bun_[o >> 4]--; unseen_total_--;
     }
-    prob = tree[num_syms + i]; prob = (prob & 0xFFFEFFFEu) >> 1;
-    if (no_escape) prob = 0; else if (prob == 0) prob = 1u << 16;
-    tree[num_syms + i] = prob; sum();
+    cnt_[o] += 0x100u; bcnt_[o >> 4] += 0x100u; cnt_total_ += 0x100u;
+    if (cnt_total_ >= 0xFF00u) halve();
+    return sym_[o];
   }
-  int decode1(bool esc) {
-    uint32_t mask = 0xFFFF0000u; int shift = 16; uint32_t upd = 0x100u << 16;
-    if (esc) { mask = 0xFFFFu; upd -= 1u; shift = 0; }
-    const uint32_t tot = (tree[1] & mask) >> shift;
+ private:
+  // slot whose cumulative count interval holds the coder's target; commits the step with the count BEFORE the update
+  int take(const uint32_t* c, const uint32_t* bc, uint32_t tot) {
     if (tot == 0) return -1;
-    const uint32_t prob = d.cul_freq(tot);
-    int i = 1; uint32_t lt = 0;
-    while (i < num_syms) {
-      tree[i] += upd;
-      const uint32_t left = (tree[2 * i] & mask) >> shift;
-      i *= 2;
-      if (prob - lt >= left) { lt += left; i++; }
-    }
-    const int symbol = i - num_syms;
-    const uint32_t sy = (tree[i] & mask) >> shift;
-    tree[i] += upd;
-    d.update(sy, lt, tot);
-    if (symbol == num_syms - 1 && (tree[1] & 0xFFFFu) == 1u) { upd = 0u - tree[i]; while (i >= 1) { tree[i] += upd; i >>= 1; } }
-    if ((tree[1] >> 16) >= 0xFF00u) rescale();
-    return symbol;
+    const uint32_t t = d_.target(tot);
+    uint32_t lt = 0; int b = 0;
+    const int nbuck = (n_ + 15) >> 4;
+    while (b < nbuck - 1 && lt + bc[b] <= t) lt += bc[b++];
+    int o = b << 4;
+    while (o < n_ - 1 && lt + c[o] <= t) lt += c[o++];
+    d_.commit(c[o], lt, tot);
+    return o;
   }
-  int decode() { int s = decode1(false); if (s == num_syms - 1) s = decode1(true); return s; }
+  int take_unseen(uint32_t tot) {
+    const uint32_t t = d_.target(tot);
+    uint32_t lt = 0; int b = 0;
+    const int nbuck = (n_ + 15) >> 4;
+    while (b < nbuck - 1 && lt + bun_[b] <= t) lt += bun_[b++];
+    int o = b << 4;
+    while (o < n_ - 1 && lt + unseen_[o] <= t) lt += unseen_[o++];
+    d_.commit(unseen_[o], lt, tot);
+    return unseen_[o] ? o : -1;
+  }
+  void halve() {                                                    // rescale (:1623-1646)
+    bool any_unseen = false;
+    for (int o = 0; o < n_; o++) {
+      if (o == esc_slot_) continue;
+      if (unseen_[o]) { any_unseen = true; continue; }
+      cnt_[o] >>= 1;
+      if (cnt_[o] == 0) { unseen_[o] = 1; any_unseen = true; }      // a count that halves to nothing makes the symbol novel again
+    }
+    uint32_t e = cnt_[esc_slot_] >> 1;
+    cnt_[esc_slot_] = any_unseen ? (e ? e : 1u) : 0u;
+    resum();
+  }
+  void resum() {
+    const int nbuck = (n_ + 15) >> 4;
+    cnt_total_ = unseen_total_ = 0;
+    for (int b = 0; b < nbuck; b++) bcnt_[b] = bun_[b] = 0;
+    for (int o = 0; o < n_; o++) { bcnt_[o >> 4] += cnt_[o]; bun_[o >> 4] += unseen_[o]; cnt_total_ += cnt_[o]; unseen_total_ += unseen_[o]; }
+  }
+  RangeDecoder& d_;
+  int n_, esc_slot_ = 0;                                            // n_ = coded symbols incl. the escape symbol (the last one)
+  uint16_t sym_[272];
+  uint32_t cnt_[272], unseen_[272], bcnt_[17], bun_[17];
+  uint32_t cnt_total_ = 0, unseen_total_ = 0;
 };
 
-struct DsmDec {                                         // DefSumModel decode side (:1327-1459)
-  HostDecoder& d; int ns; uint16_t prob[304], esc[304], upd[304], p2s[256], e2s[304]; int ucount = 0, uthresh = 128;
-  DsmDec(HostDecoder& dd, int size) : d(dd), ns(size) {
-    memset(prob, 0, sizeof prob); memset(esc, 0, sizeof esc); memset(upd, 0, sizeof upd);
-    prob[ns + 1] = 256;
-    for (int i = 0; i <= ns; i++) esc[i] = (uint16_t)i;
-    for (int i = 0; i < 256; i++) p2s[i] = (uint16_t)ns;
-    for (int i = 0; i < 304; i++) e2s[i] = (uint16_t)(i < ns ? i : 0);
-  }
-  void update(int symbol) {
-    if (symbol == ns) { if (upd[symbol] >= 40) return; if (ucount >= uthresh - 1) return; }
-    upd[symbol]++; ucount++;
-    if (ucount < uthresh) return;
-    int cum = 0, cum_esc = 0, odd = 0, i;
-    esc[0] = 0; prob[0] = 0;
-    for (i = 0; i < ns + 1; i++) {
-      const int np = ((prob[i + 1] - prob[i]) >> 1) + upd[i];
-      prob[i] = (uint16_t)cum; esc[i] = (uint16_t)cum_esc;
-      if (np) { cum += np; odd += np & 1; } else cum_esc++;
-    }
-    prob[i] = (uint16_t)cum;
-    uthresh = 256 - (cum - odd) / 2;
-    for (i = 0; i < ns + 1; i++) upd[i] = 0;
-    upd[ns] = 1; ucount = 1;
-    int j = 0, k = 0;
-    for (i = 0; i < ns + 1; i++) {
-      for (; j < prob[i + 1]; j++) p2s[j] = (uint16_t)i;
-      const int el = i + 1 <= ns ? esc[i + 1] : 0;       // escape[] has ns+1 entries in the reference
-      for (; k < el; k++) e2s[k] = (uint16_t)i;
-    }
+// DefSumModel, decode side (:1327-1459): 8-bit total, counts folded in only every `quota_` symbols.  Lookup of the symbol
+// from the 8-bit target is a direct 256-entry table rebuilt at every fold; the escape distribution is uniform over the
+// symbols whose count is still zero.
+class DeferredSumDecoder {
+ public:
+  DeferredSumDecoder(RangeDecoder& d, int size) : d_(d), esc_(size) {
+    memset(cum_, 0, sizeof cum_); memset(pend_, 0, sizeof pend_);
+    cum_[esc_ + 1] = 256;                                           // everything on the escape symbol at first
+    for (int i = 0; i <= esc_; i++) zero_rank_[i] = (uint16_t)i;
+    for (int i = 0; i < 256; i++) by_target_[i] = (uint16_t)esc_;
+    for (int i = 0; i < 304; i++) by_zero_rank_[i] = (uint16_t)(i < esc_ ? i : 0);
   }
   int decode() {
-    uint32_t p = d.cul_shift(8);
-    int symbol = p2s[p];
-    uint32_t lt = prob[symbol], sy = (uint32_t)prob[symbol + 1] - lt;
-    d.update(sy, lt, 256); update(symbol);
-    if (symbol != ns) return symbol;
-    const uint32_t tot = esc[ns];
-    if (tot == 0) return -1;
-    p = d.cul_freq(tot);
-    symbol = e2s[p];
-    lt = esc[symbol]; sy = (uint32_t)esc[symbol + 1] - lt;
-    d.update(sy, lt, tot); update(symbol);
-    return symbol;
+    int sym = by_target_[d_.target_pow2(8)];
+    d_.commit((uint32_t)cum_[sym + 1] - cum_[sym], cum_[sym], 256);
+    note(sym);
+    if (sym != esc_) return sym;
+    const uint32_t nzero = zero_rank_[esc_];
+    if (nzero == 0) return -1;
+    sym = by_zero_rank_[d_.target(nzero)];
+    d_.commit((uint32_t)zero_rank_[sym + 1] - zero_rank_[sym], zero_rank_[sym], nzero);
+    note(sym);
+    return sym;
   }
+ private:
+  void note(int sym) {                                              // :1398-1429
+    if (sym == esc_ && (pend_[sym] >= 40 || seen_ >= quota_ - 1)) return;
+    pend_[sym]++; seen_++;
+    if (seen_ < quota_) return;
+    int total = 0, zeros = 0, odd = 0;
+    for (int i = 0; i <= esc_; i++) {                               // halve the old share, add what arrived since
+      const int c = ((cum_[i + 1] - cum_[i]) >> 1) + pend_[i];
+      cum_[i] = (uint16_t)total; zero_rank_[i] = (uint16_t)zeros;
+      if (c) { total += c; odd += c & 1; } else zeros++;
+    }
+    cum_[esc_ + 1] = (uint16_t)total;
+    quota_ = 256 - (total - odd) / 2;
+    memset(pend_, 0, sizeof pend_);
+    pend_[esc_] = 1; seen_ = 1;
+    int t = 0, z = 0;
+    for (int i = 0; i <= esc_; i++) {
+      for (; t < cum_[i + 1]; t++) by_target_[t] = (uint16_t)i;
+      const int ze = i + 1 <= esc_ ? zero_rank_[i + 1] : 0;         // the reference's escape[] has esc_+1 entries
+      for (; z < ze; z++) by_zero_rank_[z] = (uint16_t)i;
+    }
+  }
+  RangeDecoder& d_;
+  int esc_;                                                         // number of ordinary symbols = index of the escape symbol
+  uint16_t cum_[304], zero_rank_[304], pend_[304], by_target_[256], by_zero_rank_[304];
+  int seen_ = 0, quota_ = 128;
 };
 
-}  // namespace
+struct BwtcBlocks {                     // output of the serial stage: the BWT columns of all blocks, back to back
+  std::vector<uint8_t> cols;
+  std::vector<uint32_t> lens, pidx;
+  int level = 0;
+};
 
-extern "C" int cjs_bwtc_decompress(const uint8_t* in, size_t n, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
-  if (!out || !out_n) return CJS_E_INVALID_ARG;
-  *out = nullptr; *out_n = 0;
-  CJS_TRY(select_device(opts));
+// header, per-block flag / length / primary index / use-tree, symbol decode, RLE2 + MTF inverse (:1827-1913)
+int bwtc_entropy_decode(const uint8_t* in, size_t n, BwtcBlocks& B) {
   if (n < 4 || in[0] != 'b' || in[1] != 'w' || in[2] != 't' || in[3] != 'c') return CJS_E_BAD_MAGIC;     // :559-565
   size_t p = 4;
   for (;;) { if (p >= n) return CJS_E_DATA_ERROR; if (in[p++] & 0x80) break; }                          // readUnsignedNumber :621-633
-  HostDecoder d{in, n, p};
-  d.start();
-  const uint32_t lv = d.cul_shift(8); d.update(1, lv, 256);                                            // decodeByte :1830
+  RangeDecoder d(in, n, p);
+  d.begin();
+  const uint32_t lv = d.target_pow2(8); d.commit(1, lv, 256);                                          // decodeByte :1830
   if (lv < 1 || lv > 9) return CJS_E_DATA_ERROR;
+  B.level = (int)lv;
   const bool fast = lv <= 5;
   const uint32_t bs = lv * 100000u;
-  std::vector<uint8_t> T;                                // BWT columns of all blocks, stride bs
-  std::vector<uint32_t> lens, pidx;
+  static const bool dbg = getenv("CJS_DEBUG") != nullptr;
   for (;;) {
-    const uint32_t ind = d.cul_freq(3); d.update(1, ind, 3);
+    const uint32_t flag = d.target(3); d.commit(1, flag, 3);
     uint32_t length;
-    if (ind == 0) length = bs;
-    else if (ind == 1) { length = logdist_dec(d, (int)bs); if (length > bs) return CJS_E_DATA_ERROR; }
+    if (flag == 0) length = bs;
+    else if (flag == 1) { length = d.log_distance((int)bs); if (length > bs) return CJS_E_DATA_ERROR; }
     else break;
-    const uint32_t pi = logdist_dec(d, (int)bs);
+    const uint32_t pi = d.log_distance((int)bs);
     uint16_t tree[512]; memset(tree, 0, sizeof tree); tree[0] = 1;                                     // use-tree :1859-1874
     for (int i = 1; i < 512; i++) {
       const int parent = i >> 1, full = 1 << (9 - fls32((uint32_t)i));
       if (tree[parent] == 0 || tree[parent] == full * 2) tree[i] = tree[parent] >> 1;
       else if (i >= 256) tree[i] = (uint16_t)d.bit();
-      else { const uint32_t v = d.cul_freq(3); d.update(1, v, 3); tree[i] = (uint16_t)(v == 2 ? (uint32_t)full : v); }
+      else { const uint32_t v = d.target(3); d.commit(1, v, 3); tree[i] = (uint16_t)(v == 2 ? (uint32_t)full : v); }
     }
-    uint8_t M[256]; int asz = 0;
-    for (int i = 0; i < 256; i++) if (tree[256 + i]) M[asz++] = (uint8_t)i;
-    const size_t base = T.size();
-    T.resize(base + bs);
-    uint8_t* b = T.data() + base;
-    FenDec* fm = fast ? nullptr : new FenDec(d, asz + 1);
-    DsmDec* dm = fast ? new DsmDec(d, asz + 1) : nullptr;
-    uint64_t val = 1; uint32_t i = 0; bool bad = false;
-    while (i < length) {                                                                               // :1888-1903
-      const int c = fast ? dm->decode() : fm->decode();
-      if (c < 0 || d.overrun()) { bad = true; break; }
-      if (c == 0) { if (i + val > length) { bad = true; break; } for (uint64_t j = 0; j < val; j++) b[i++] = 0; val *= 2; }
-      else if (c == 1) { if (i + 2 * val > length) { bad = true; break; } for (uint64_t j = 0; j < 2 * val; j++) b[i++] = 0; val *= 2; }
-      else { val = 1; if (c - 1 >= asz) { bad = true; break; } b[i++] = (uint8_t)(c - 1); }
+    uint8_t order[256]; int asz = 0;
+    for (int i = 0; i < 256; i++) if (tree[256 + i]) order[asz++] = (uint8_t)i;
+    if (d.exhausted()) return CJS_E_DATA_ERROR;
+    // the block is stored at its decoded length (a forged header cannot make the host reserve a full block per 13 bits)
+    const size_t base = B.cols.size();
+    B.cols.resize(base + length);
+    uint8_t* b = B.cols.data() + base;
+    uint64_t run = 1; uint32_t i = 0; bool bad = false;
+    {
+      RankModelDecoder* rm = fast ? nullptr : new RankModelDecoder(d, asz + 1);
+      DeferredSumDecoder* dm = fast ? new DeferredSumDecoder(d, asz + 1) : nullptr;
+      while (i < length) {                                                                             // :1888-1903
+        const int c = fast ? dm->decode() : rm->decode();
+        if (c < 0 || d.exhausted()) { bad = true; break; }
+        if (c <= 1) {                                                // RUNA / RUNB: bijective base-2 digits of a zero run
+          const uint64_t add = run << c;
+          if (i + add > length) { bad = true; break; }
+          memset(b + i, 0, (size_t)add); i += (uint32_t)add; run *= 2;
+        } else { run = 1; if (c - 1 >= asz) { bad = true; break; } b[i++] = (uint8_t)(c - 1); }
+      }
+      delete rm; delete dm;
     }
-    delete fm; delete dm;
-    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwtc dec] block %zu: length %u pidx %u asz %d decoded %u bad %d inpos %zu/%zu\n", lens.size(), length, pi, asz, i, (int)bad, d.pos, n);
-    if (bad) return CJS_E_DATA_ERROR;
+    if (dbg) fprintf(stderr, "[cjs bwtc dec] block %zu: length %u pidx %u asz %d decoded %u bad %d inpos %zu/%zu\n", B.lens.size(), length, pi, asz, i, (int)bad, d.consumed(), n);
+    if (bad || pi > length) return CJS_E_DATA_ERROR;
     for (i = 0; i < length; i++) {                                                                     // MTF decode :1905-1913
-      int j = b[i]; const uint8_t c = M[j];
+      const int j = b[i]; const uint8_t c = order[j];
       b[i] = c;
-      for (; j > 0; j--) M[j] = M[j - 1];
-      M[0] = c;
+      if (j) { memmove(order + 1, order, (size_t)j); order[0] = c; }
     }
-    if (pi > length) return CJS_E_DATA_ERROR;
-    lens.push_back(length); pidx.push_back(pi);
+    if (length == 0) { B.cols.resize(base); continue; }             // an empty block contributes nothing (unbwtransform of 0 bytes)
+    B.lens.push_back(length); B.pidx.push_back(pi);
   }
-  const uint32_t nb = (uint32_t)lens.size();
-  uint64_t total = 0;
-  for (uint32_t k = 0; k < nb; k++) total += lens[k];
-  uint8_t* host = (uint8_t*)malloc(total ? total : 1);
+  return 0;
+}
+
+}  // namespace
+
+// Stage-level entry point (host logic only, no device needed): the serial entropy stage of BWTC.decompressFile.
+// cols receives the BWT columns of all non-empty blocks back to back (malloc'd, cjs_free); lens/pidx per block.
+extern "C" long cjs_stage_bwtc_entropy_decode(const uint8_t* in, size_t n, uint8_t** cols, size_t* cols_n, uint32_t* lens, uint32_t* pidx, long cap,
+                                              int* level) {
+  if (!cols || !cols_n) return CJS_E_INVALID_ARG;
+  *cols = nullptr; *cols_n = 0;
+  CJS_GUARD_BEGIN
+  BwtcBlocks B;
+  const int rc = bwtc_entropy_decode(in, n, B);
+  if (rc) return (long)rc;
+  if (level) *level = B.level;
+  uint8_t* c = (uint8_t*)malloc(B.cols.size() ? B.cols.size() : 1);
+  if (!c) return (long)CJS_E_OUT_OF_MEMORY;
+  if (!B.cols.empty()) memcpy(c, B.cols.data(), B.cols.size());
+  for (size_t k = 0; k < B.lens.size() && (long)k < cap; k++) { if (lens) lens[k] = B.lens[k]; if (pidx) pidx[k] = B.pidx[k]; }
+  *cols = c; *cols_n = B.cols.size();
+  return (long)B.lens.size();
+  CJS_GUARD_END((long)CJS_E_OUT_OF_MEMORY, (long)CJS_E_HIP)
+}
+
+extern "C" int cjs_bwtc_decompress(const uint8_t* in, size_t n, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
+  if (!out || !out_n) return CJS_E_INVALID_ARG;
+  *out = nullptr; *out_n = 0;
+  clear_detail();
+  CJS_GUARD_BEGIN
+  CJS_TRY(select_device(opts));
+  BwtcBlocks B;
+  CJS_TRY(bwtc_entropy_decode(in, n, B));
+  const uint32_t nb = (uint32_t)B.lens.size();
+  const uint64_t total = B.cols.size();
+  uint8_t* host = (uint8_t*)malloc(total ? (size_t)total : 1);
   if (!host) return CJS_E_OUT_OF_MEMORY;
   if (nb) {
     // n <= 1 blocks: unbwtransform copies (:1149-1152); handled by the same kernels (a 1-element chain)
     uint8_t *d_T = nullptr, *d_out = nullptr; hipStream_t s = nullptr;
     int rc = 0;
-    if (hipMalloc((void**)&d_T, T.size() + 64) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
-    if (!rc && hipMalloc((void**)&d_out, total + 64) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
+    if (hipMalloc((void**)&d_T, (size_t)total + 64) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
+    if (!rc && hipMalloc((void**)&d_out, (size_t)total + 64) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
     if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && hipMemcpyAsync(d_T, T.data(), T.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc) rc = ibwt_sentinel_run(s, d_T, bs, nb, lens.data(), pidx.data(), d_out);
-    if (!rc && total && hipMemcpy(host, d_out, total, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemcpyAsync(d_T, B.cols.data(), (size_t)total, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc) rc = ibwt_sentinel_run(s, d_T, (uint32_t)B.level * 100000u, nb, B.lens.data(), B.pidx.data(), d_out);
+    if (!rc && total && hipMemcpy(host, d_out, (size_t)total, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
     if (s) (void)hipStreamDestroy(s);
     if (d_T) (void)hipFree(d_T);
     if (d_out) (void)hipFree(d_out);
@@ -779,4 +869,5 @@ extern "C" int cjs_bwtc_decompress(const uint8_t* in, size_t n, uint8_t** out, s
   }
   *out = host; *out_n = (size_t)total;
   return 0;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <new>
 #include "cjs_hip.h"
 
 #define CJS_HIP_TRY(expr)                                                                   \
@@ -17,6 +18,17 @@
 #define CJS_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 namespace cjs {
+
+// thread-local detail text behind cjs_last_error_detail() (api.hip)
+void clear_detail();
+void set_detail(const char* fmt, ...);
+
+// Body of an extern "C" entry point: C++ exceptions (std::bad_alloc from a container fed by untrusted sizes) never
+// cross the C ABI, they become return codes.
+#define CJS_GUARD_BEGIN try {
+#define CJS_GUARD_END(oom_value, other_value)                          \
+  } catch (const std::bad_alloc&) { return (oom_value); }              \
+  catch (...) { return (other_value); }
 
 // simple device arena: one hipMalloc, bump allocation, 256-byte aligned
 struct Arena {
@@ -67,8 +79,8 @@ struct BwtWork {
   uint32_t* gord = nullptr;
   uint32_t* R = nullptr;
   uint32_t* SA = nullptr;
-  uint32_t* hist = nullptr;      // 256 * tiles
-  uint32_t* bintot = nullptr;    // 256
+  uint32_t* hist = nullptr;      // hist_words(tiles): 256 per tile (tile-major) + the chunk sums of the long-segment scan
+  uint32_t* bintot = nullptr;    // 256 per segment
   uint32_t* tile_cnt = nullptr;  // 3 * tiles (+ scanned copies)
   uint32_t* counters = nullptr;  // 16: [0] survivors [1] groups [8] tile ticket [9] look-back error
   uint32_t* ghist = nullptr;     // [8][256] digit histograms + [8][256] their exclusive scans (onesweep passes)
@@ -78,6 +90,7 @@ struct BwtWork {
   // segmented sorts round every block up to whole tiles: room for one extra tile per 64 Ki elements
   static size_t hist_tiles_for(size_t cap) { return (cap + RS_TILE - 1) / RS_TILE + cap / 65536 + 258; }
   static size_t segs_for(size_t cap) { return cap / 65536 + 2; }
+  static size_t hist_words(size_t tiles) { return 256 * (tiles + tiles / 64 + 2); }
   static size_t bytes_needed(size_t cap);
   int carve(Arena& a, size_t cap);
 };

@@ -24,6 +24,7 @@
 #include <chrono>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 
 namespace cjs {
@@ -50,10 +51,11 @@ struct BlockOut {
 };
 
 // ---------------------------------------------------------------- 1. magic scan
-__global__ __launch_bounds__(256) void bz_magic_scan(const uint8_t* __restrict__ in, uint64_t n, Cand* __restrict__ out, uint32_t cap,
+// `in` is addressed by absolute stream byte; bytes [byte0, byte1) are tested as candidate starts, reads stay below n
+__global__ __launch_bounds__(256) void bz_magic_scan(const uint8_t* __restrict__ in, uint64_t byte0, uint64_t byte1, uint64_t n, Cand* __restrict__ out, uint32_t cap,
                                                      uint32_t* __restrict__ count) {
-  const uint64_t byte = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (byte + 6 > n) return;
+  const uint64_t byte = byte0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (byte >= byte1 || byte + 6 > n) return;
   uint64_t w = 0;
   for (int i = 0; i < 7; i++) w = (w << 8) | (byte + i < n ? in[byte + i] : 0);      // 56 bits
   for (int b = 0; b < 8; b++) {
@@ -898,13 +900,15 @@ __global__ void ib_make_crc_ranges(const IbBlock* __restrict__ blocks, uint32_t 
 
 // ---------------------------------------------------------------- inverse sentinel BWT of a batch (used by BWTC.decompressFile)
 namespace cjs {
-int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32_t nb, const uint32_t* lens, const uint32_t* pidx, uint8_t* d_out) {
-  if (!nb) return 0;
+// d_T holds the blocks back to back (block k at the sum of the earlier lengths), max_len bounds every block length.
+// Blocks are processed in slabs of <= 65535 (grid.y of the per-block kernels) and <= 2^28 elements (bounded scratch).
+static int ibwt_sentinel_slab(hipStream_t s, const uint8_t* d_T, uint32_t max_len, uint32_t nb, const uint32_t* lens, const uint32_t* pidx, uint8_t* d_out) {
   std::vector<IbBlock> chain(nb);
   uint64_t M64 = 0;
   for (uint32_t k = 0; k < nb; k++) {
     IbBlock& b = chain[k];
-    b.cand = k; b.count = lens[k]; b.orig = pidx[k]; b.off = (uint32_t)M64; b.out_off = M64; b.out_len = lens[k]; b.crc = 0;
+    b.cand = (uint32_t)M64;                       // with a row stride of 1 the "candidate index" is the block's byte offset in d_T
+    b.count = lens[k]; b.orig = pidx[k]; b.off = (uint32_t)M64; b.out_off = M64; b.out_len = lens[k]; b.crc = 0;
     M64 += lens[k];
   }
   if (M64 >= 0xFFFFF000ull) return CJS_E_UNSUPPORTED;
@@ -914,7 +918,7 @@ int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32
   auto cleanup = [&]() { for (void* p : to_free) (void)hipFree(p); };
   IbBlock* d_blocks = nullptr; uint32_t *d_key0 = nullptr, *d_key1 = nullptr, *d_val0 = nullptr, *d_val1 = nullptr;
   uint32_t *d_snext = nullptr, *d_ssteps = nullptr, *d_srank = nullptr; int32_t* d_err = nullptr;
-  const uint32_t spl_stride = stride / SPL + 4;
+  const uint32_t spl_stride = max_len / SPL + 4;
   BwtWork sw;
   int rc = dmalloc((void**)&d_blocks, sizeof(IbBlock) * nb);
   if (!rc) rc = dmalloc((void**)&d_key0, 4 * (size_t)M + 64); if (!rc) rc = dmalloc((void**)&d_key1, 4 * (size_t)M + 64);
@@ -922,23 +926,23 @@ int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32
   if (!rc) rc = dmalloc((void**)&d_snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_ssteps, 4 * (size_t)nb * spl_stride);
   if (!rc) rc = dmalloc((void**)&d_srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_err, 4 * (size_t)nb);
   const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
-  if (!rc) rc = dmalloc((void**)&sw.hist, 256 * T * 4); if (!rc) rc = dmalloc((void**)&sw.bintot, 256 * 4);
+  if (!rc) rc = dmalloc((void**)&sw.hist, BwtWork::hist_words(T) * 4); if (!rc) rc = dmalloc((void**)&sw.bintot, 256 * 4);
   sw.hist_tiles = (uint32_t)T; sw.bintot_segs = 1;
   if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
   if (rc) { cleanup(); return rc; }
-  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_T, stride, d_blocks, d_key0, d_val0);
+  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_T, 1u, d_blocks, d_key0, d_val0);
   int cur = 0;
   int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
   rc = radix_passes_public<uint32_t>(s, sw, d_key0, d_val0, d_key1, d_val1, cur, M, 0, kbits);
   if (rc) { cleanup(); return rc; }
   uint32_t* sval = cur ? d_val1 : d_val0;
   uint32_t* d_dbuf = cur ? d_key0 : d_key1;
-  hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_T, stride, d_blocks, sval, d_dbuf);
+  hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_T, 1u, d_blocks, sval, d_dbuf);
   hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 1);
   hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
   hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_out, 1);
   std::vector<int32_t> errs(nb);
-  if (hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
   cleanup();
   if (rc) return rc;
   // The chain visits n distinct rows and then re-enters at row pidx (the step the reference computes last and never
@@ -949,217 +953,428 @@ int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t stride, uint32
   }
   return 0;
 }
+int ibwt_sentinel_run(hipStream_t s, const uint8_t* d_T, uint32_t max_len, uint32_t nb, const uint32_t* lens, const uint32_t* pidx, uint8_t* d_out) {
+  uint64_t base = 0;
+  for (uint32_t k0 = 0; k0 < nb;) {
+    uint32_t k1 = k0; uint64_t el = 0;
+    while (k1 < nb && k1 - k0 < 65535u && (k1 == k0 || el + lens[k1] <= (1ull << 28))) el += lens[k1++];
+    CJS_TRY(ibwt_sentinel_slab(s, d_T + base, max_len, k1 - k0, lens + k0, pidx + k0, d_out + base));
+    base += el; k0 = k1;
+  }
+  return 0;
+}
 }  // namespace cjs
 
 // ---------------------------------------------------------------- host driver
 // mode 0: Bunzip.decode (:1769-1796); mode 1: Bunzip.table (:1823-1863) -> (bit position, size) per block, no bytes;
-// mode 2: Bunzip.decodeBlock (:1797-1818) -> the single block whose magic starts at `at_bit`
+// mode 2: Bunzip.decodeBlock (:1797-1818) -> the single block whose magic starts at `at_bit`.
+//
+// The job is cut into per-device shares (SURVEY §8e "Bzip2 decompress"; cjs_opts.n_devices / CJS_DEVICES, one host thread
+// per share; several shares may sit on one GPU):
+//   A  per share   upload its byte range (+ one worst-case block of overlap), magic scan, speculative decode of every
+//                  candidate that STARTS in the share
+//   -  host        chain walk 32 -> end(block 0) -> end(block 1) ... over all shares' candidates: stream CRC fold,
+//                  multistream restarts (each stream keeps its own level, :1787-1792)
+//   B  per share   inverse BWT of the chain blocks it decoded, in batches (bounded scratch), RLE1 length pass
+//   -  host        exclusive prefix sum of the decoded lengths -> output offsets
+//   C  per share   RLE1 expansion + block CRCs per batch, D2H straight to the final offsets
+// No data moves between devices; the exchanged quantities are (end bit, count, crc) per candidate and a length per block.
+namespace {
+
+constexpr uint64_t DEC_BATCH_ELEMS = 1ull << 28;      // BWT bytes per inverse-BWT batch (scratch ~ 21 B each)
+constexpr uint32_t DEC_BATCH_BLOCKS = 65535;          // grid.y of the per-block kernels
+
+struct DecShare {
+  int device = 0, rc = 0;
+  hipStream_t s = nullptr;
+  std::vector<void*> bufs;
+  uint64_t lo = 0, hi = 0;            // candidates starting in bytes [lo, hi) are this share's
+  uint64_t up_lo = 0, up_hi = 0;      // uploaded byte range
+  const uint8_t* d_in = nullptr;      // addressed by absolute byte: d_in[b] is valid for up_lo <= b < up_hi
+  std::vector<Cand> cands;            // sorted by bit
+  std::vector<BlockOut> bos;
+  uint8_t* d_tt = nullptr;            // decoded BWT bytes, tt_stride per candidate
+  size_t cand_base = 0;               // index of cands[0] in the job's candidate list
+  // chain part
+  size_t c0 = 0, c1 = 0;              // chain blocks [c0, c1) were decoded here
+  uint8_t* d_w = nullptr;             // pre-RLE1 bytes of those blocks, contiguous in chain order
+  std::vector<uint64_t> ebase;        // element offset of block c0+i inside d_w (size c1-c0+1)
+  double ms_a = 0, ms_b = 0, ms_c = 0;
+  char detail[96] = {0};            // error detail found by this share's worker thread (the detail text is per calling thread)
+  int take(void** p, size_t bytes) { *p = DevPool::take(bytes); if (!*p) return (int)CJS_E_OUT_OF_MEMORY; bufs.push_back(*p); return 0; }
+  void drop(void* p) { for (size_t i = 0; i < bufs.size(); i++) if (bufs[i] == p) { bufs.erase(bufs.begin() + (long)i); break; } DevPool::give(p); }
+  void release() {
+    if (hipSetDevice(device) != hipSuccess) return;
+    if (s) (void)hipStreamSynchronize(s);
+    for (void* p : bufs) DevPool::give(p);
+    bufs.clear();
+    if (s) (void)hipStreamDestroy(s);
+    s = nullptr;
+  }
+};
+
+struct DecJob {
+  const uint8_t* in = nullptr; size_t n = 0;
+  uint32_t tt_stride = 0;             // = dbuf size of the largest level in the input
+  int mode = 0;
+  std::vector<IbBlock> chain;         // all valid blocks in stream order (cand = index local to the decoding share)
+  std::vector<uint64_t> chain_bits;
+  std::vector<uint64_t> out_off;      // size chain.size()+1
+  uint8_t* host = nullptr;            // final output (mode 0 / 2)
+  bool timing = false;
+};
+
+double ms_since(std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); }
+
+// ---- phase A
+void dec_phase_a(DecJob* J, DecShare* S) {
+  const auto T0 = std::chrono::steady_clock::now();
+  if (hipSetDevice(S->device) != hipSuccess || hipStreamCreate(&S->s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  hipStream_t s = S->s;
+  const size_t up_n = (size_t)(S->up_hi - S->up_lo);
+  uint8_t* d_raw = nullptr; Cand* d_cand = nullptr; uint32_t* d_count = nullptr;
+  const uint32_t cand_cap = (uint32_t)((S->hi - S->lo) / 64 + 1024);
+  int rc = S->take((void**)&d_raw, up_n + 256 + 16);
+  if (!rc) rc = S->take((void**)&d_cand, sizeof(Cand) * cand_cap);
+  if (!rc) rc = S->take((void**)&d_count, 64);
+  if (rc) { S->rc = rc; return; }
+  // keep the dword phase of the stream: the decoders fetch aligned big-endian words by absolute word index
+  uint8_t* d_al = d_raw + (S->up_lo & 3u);
+  S->d_in = d_al - S->up_lo;
+  if (hipMemcpyAsync(d_al, J->in + S->up_lo, up_n, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(d_count, 0, 64, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  if (S->hi > S->lo) hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((S->hi - S->lo + 255) / 256)), dim3(256), 0, s, S->d_in, S->lo, S->hi, S->up_hi, d_cand, cand_cap, d_count);
+  uint32_t ncand = 0;
+  if (hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  if (ncand > cand_cap) { S->rc = CJS_E_DATA_ERROR; return; }
+  S->cands.resize(ncand);
+  if (ncand && hipMemcpy(S->cands.data(), d_cand, sizeof(Cand) * ncand, hipMemcpyDeviceToHost) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  std::sort(S->cands.begin(), S->cands.end(), [](const Cand& a, const Cand& b) { return a.bit < b.bit; });
+  if (ncand && hipMemcpy(d_cand, S->cands.data(), sizeof(Cand) * ncand, hipMemcpyHostToDevice) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  S->bos.resize(ncand);
+  if (!ncand) { S->ms_a = ms_since(T0); return; }
+  uint32_t* d_hist = nullptr; BlockOut* d_bo = nullptr;
+  static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
+  static const bool v2 = getenv("CJS_DECODE_V2") != nullptr;      // the one-wave cooperative loop
+  rc = S->take((void**)&S->d_tt, (size_t)ncand * J->tt_stride);
+  if (!rc && (v1 || v2)) rc = S->take((void**)&d_hist, (size_t)ncand * 256 * 4);
+  if (!rc) rc = S->take((void**)&d_bo, sizeof(BlockOut) * ncand);
+  if (rc) { S->rc = rc; return; }
+  const uint32_t dsz = J->tt_stride;
+  if (v1) hipLaunchKernelGGL(bz_decode_block<1>, dim3(ncand), dim3(64), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_hist, d_bo);
+  else if (v2) hipLaunchKernelGGL(bz_decode_block<2>, dim3(ncand), dim3(64), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_hist, d_bo);
+  else hipLaunchKernelGGL(bz_decode_block_pipe, dim3(ncand), dim3(128), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_bo);
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  if (getenv("CJS_DEBUG")) {
+    uint64_t clk[8];
+    if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
+      if (v1 || v2) fprintf(stderr, "[cjs dec] candidate 0: header+selectors+lengths %.1f us, tables %.1f us, symbol loop %.1f us\n", (clk[1] - clk[0]) / 100.0, (clk[2] - clk[1]) / 100.0, (clk[3] - clk[2]) / 100.0);
+      else fprintf(stderr, "[cjs dec] candidate 0 (two-wave pipeline): %llu symbols; producer %.1f us, %llu rounds, waited for ring space %llu times; consumer %.1f us, %llu batches, found the ring empty %llu times\n",
+                   (unsigned long long)clk[7], clk[6] / 100.0, (unsigned long long)clk[5], (unsigned long long)clk[4], clk[2] / 100.0, (unsigned long long)clk[1], (unsigned long long)clk[0]);
+    }
+    fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
+            (unsigned long long)S->hi, (unsigned long long)S->up_lo, (unsigned long long)S->up_hi, up_n, ncand);
+  }
+  S->drop(d_cand); S->drop(d_count); S->drop(d_bo); if (d_hist) S->drop(d_hist);
+  S->ms_a = ms_since(T0);
+}
+
+// scratch of one inverse-BWT batch
+struct IbScratch {
+  IbBlock* d_blocks = nullptr; uint32_t *key0 = nullptr, *key1 = nullptr, *val0 = nullptr, *val1 = nullptr;
+  uint32_t *snext = nullptr, *ssteps = nullptr, *srank = nullptr; int32_t* d_err = nullptr;
+  BwtWork sw;
+};
+
+// batches of the share's chain blocks: [b0, b1) with <= DEC_BATCH_ELEMS elements and <= DEC_BATCH_BLOCKS blocks
+size_t dec_next_batch(const DecJob* J, size_t b0, size_t c1) {
+  uint64_t el = 0; size_t b = b0;
+  while (b < c1 && b - b0 < DEC_BATCH_BLOCKS && (b == b0 || el + J->chain[b].count <= DEC_BATCH_ELEMS)) { el += J->chain[b].count; b++; }
+  return b;
+}
+
+// ---- phase B: inverse BWT (T vector by a stable radix pass, splitter list ranking, second walk) + RLE1 length pass
+void dec_phase_b(DecJob* J, DecShare* S) {
+  if (S->c1 <= S->c0) return;
+  const auto T0 = std::chrono::steady_clock::now();
+  if (hipSetDevice(S->device) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  hipStream_t s = S->s;
+  const size_t nbk = S->c1 - S->c0;
+  S->ebase.assign(nbk + 1, 0);
+  for (size_t i = 0; i < nbk; i++) S->ebase[i + 1] = S->ebase[i] + J->chain[S->c0 + i].count;
+  int rc = S->take((void**)&S->d_w, (size_t)S->ebase[nbk] + 64);
+  if (rc) { S->rc = rc; return; }
+  const uint32_t spl_stride = J->tt_stride / SPL + 4;
+  for (size_t b0 = S->c0; b0 < S->c1 && !rc;) {
+    const size_t b1 = dec_next_batch(J, b0, S->c1);
+    const uint32_t nb = (uint32_t)(b1 - b0);
+    const uint64_t e0 = S->ebase[b0 - S->c0], M64 = S->ebase[b1 - S->c0] - e0;
+    if (M64 >= 0xFFFFF000ull) { rc = CJS_E_UNSUPPORTED; break; }     // a single block list beyond the batch limit cannot happen (count <= 900000)
+    const uint32_t M = (uint32_t)M64;
+    for (size_t k = b0; k < b1; k++) J->chain[k].off = (uint32_t)(S->ebase[k - S->c0] - e0);
+    IbScratch q;
+    rc = S->take((void**)&q.d_blocks, sizeof(IbBlock) * nb);
+    if (!rc) rc = S->take((void**)&q.key0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.key1, 4 * (size_t)M + 64);
+    if (!rc) rc = S->take((void**)&q.val0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.val1, 4 * (size_t)M + 64);
+    if (!rc) rc = S->take((void**)&q.snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.ssteps, 4 * (size_t)nb * spl_stride);
+    if (!rc) rc = S->take((void**)&q.srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.d_err, 4 * (size_t)nb);
+    const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
+    if (!rc) rc = S->take((void**)&q.sw.hist, BwtWork::hist_words(T) * 4); if (!rc) rc = S->take((void**)&q.sw.bintot, 256 * 4);
+    q.sw.hist_tiles = (uint32_t)T; q.sw.bintot_segs = 1;
+    if (!rc && hipMemcpyAsync(q.d_blocks, J->chain.data() + b0, sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipMemsetAsync(q.d_err, 0, 4 * (size_t)nb, s) != hipSuccess) rc = CJS_E_HIP;
+    if (rc) break;
+    uint8_t* d_wb = S->d_w + e0;
+    hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, S->d_tt, J->tt_stride, q.d_blocks, q.key0, q.val0);
+    int cur = 0;
+    int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
+    rc = radix_passes_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, M, 0, kbits);
+    if (rc) break;
+    uint32_t* sval = cur ? q.val1 : q.val0;
+    uint32_t* d_dbuf = cur ? q.key0 : q.key1;                      // the buffer the sort is not sitting in
+    hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, S->d_tt, J->tt_stride, q.d_blocks, sval, d_dbuf);
+    hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, q.d_blocks, spl_stride, q.snext, q.ssteps, 0);
+    hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, q.d_blocks, nb, spl_stride, q.snext, q.ssteps, q.srank, q.d_err);
+    hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, q.d_blocks, spl_stride, q.srank, q.ssteps, d_wb, 0);
+    hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, q.d_blocks, q.d_err, d_wb);
+    hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_wb, q.d_blocks, (uint8_t*)nullptr, 0);
+    std::vector<int32_t> errs(nb);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(J->chain.data() + b0, q.d_blocks, sizeof(IbBlock) * nb, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(errs.data(), q.d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = CJS_E_HIP; break; }
+    for (uint32_t k = 0; k < nb; k++) if (errs[k] <= 0) rc = CJS_E_DATA_ERROR;      // cannot happen: the walk makes >= 1 step
+    S->drop(q.d_blocks); S->drop(q.key0); S->drop(q.key1); S->drop(q.val0); S->drop(q.val1); S->drop(q.snext); S->drop(q.ssteps);
+    S->drop(q.srank); S->drop(q.d_err); S->drop(q.sw.hist); S->drop(q.sw.bintot);
+    b0 = b1;
+  }
+  if (S->d_tt) { S->drop(S->d_tt); S->d_tt = nullptr; }
+  S->rc = rc;
+  S->ms_b = ms_since(T0);
+}
+
+// ---- phase C: RLE1 expansion to the final byte offsets, block CRC check, D2H
+void dec_phase_c(DecJob* J, DecShare* S) {
+  if (S->c1 <= S->c0) return;
+  const auto T0 = std::chrono::steady_clock::now();
+  if (hipSetDevice(S->device) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  hipStream_t s = S->s;
+  int rc = 0;
+  for (size_t b0 = S->c0; b0 < S->c1 && !rc;) {
+    const size_t b1 = dec_next_batch(J, b0, S->c1);
+    const uint32_t nb = (uint32_t)(b1 - b0);
+    const uint64_t e0 = S->ebase[b0 - S->c0], o0 = J->out_off[b0], obytes = J->out_off[b1] - o0;
+    std::vector<IbBlock> blk(J->chain.begin() + (long)b0, J->chain.begin() + (long)b1);
+    uint32_t need_segs = 1;
+    for (uint32_t k = 0; k < nb; k++) {
+      blk[k].off = (uint32_t)(S->ebase[b0 + k - S->c0] - e0);
+      blk[k].out_off = J->out_off[b0 + k] - o0;                   // inside the batch's output buffer
+      const uint32_t sg = (uint32_t)((blk[k].out_len + 16383) / 16384 + 1);
+      if (sg > need_segs) need_segs = sg;
+    }
+    IbBlock* d_blocks = nullptr; uint8_t* d_out = nullptr; RleBlock* d_ranges = nullptr; uint32_t *d_nb = nullptr, *d_seg = nullptr, *d_crc = nullptr;
+    rc = S->take((void**)&d_blocks, sizeof(IbBlock) * nb);
+    if (!rc) rc = S->take((void**)&d_out, (size_t)obytes + 64);
+    if (!rc) rc = S->take((void**)&d_ranges, sizeof(RleBlock) * nb);
+    if (!rc) rc = S->take((void**)&d_nb, 64);
+    if (!rc) rc = S->take((void**)&d_seg, 4 * (size_t)nb * need_segs);
+    if (!rc) rc = S->take((void**)&d_crc, 4 * (size_t)nb);
+    if (!rc && hipMemcpyAsync(d_blocks, blk.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+    if (rc) break;
+    hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, S->d_w + e0, d_blocks, d_out, 1);
+    hipLaunchKernelGGL(ib_make_crc_ranges, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, d_ranges, d_nb);
+    rc = crc_ranges(s, d_out, d_ranges, d_nb, nb, need_segs, d_seg, d_crc);
+    std::vector<uint32_t> crcs(nb);
+    if (!rc && hipMemcpyAsync(crcs.data(), d_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && J->host && obytes && hipMemcpyAsync(J->host + o0, d_out, (size_t)obytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc) for (uint32_t k = 0; k < nb; k++) if (crcs[k] != blk[k].crc) {                                   // Bad block CRC (:1756-1761)
+      snprintf(S->detail, sizeof S->detail, "Bad block CRC (got %x expected %x)", crcs[k], blk[k].crc);
+      if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block %zu: Bad block CRC (got %08x expected %08x) out_len %u\n", b0 + k, crcs[k], blk[k].crc, blk[k].out_len);
+      rc = CJS_E_DATA_ERROR; break;
+    }
+    S->drop(d_blocks); S->drop(d_out); S->drop(d_ranges); S->drop(d_nb); S->drop(d_seg); S->drop(d_crc);
+    b0 = b1;
+  }
+  S->rc = rc;
+  S->ms_c = ms_since(T0);
+}
+
+template <typename F>
+int for_each_share(std::vector<DecShare>& sh, DecJob* J, F fn) {
+  if (sh.size() == 1) fn(J, &sh[0]);
+  else {
+    std::vector<std::thread> th;
+    for (auto& x : sh) th.emplace_back(fn, J, &x);
+    for (auto& t : th) t.join();
+  }
+  for (auto& x : sh) if (x.rc) { if (x.detail[0]) set_detail("%s", x.detail); return x.rc; }
+  return 0;
+}
+
+}  // namespace
+
 static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, uint64_t at_bit, uint8_t** out, size_t* out_n,
                        uint64_t* tab_pos, uint32_t* tab_size, long tab_cap, long* tab_n, const cjs_opts* opts) {
   if (out) *out = nullptr;
   if (out_n) *out_n = 0;
   if (tab_n) *tab_n = 0;
+  clear_detail();
   CJS_TRY(select_device(opts));
   // _start_bunzip (:1408-1427)
-  if (n < 4 || in[0] != 'B' || in[1] != 'Z' || in[2] != 'h') return CJS_E_NOT_BZIP_DATA;
+  if (n < 4 || in[0] != 'B' || in[1] != 'Z' || in[2] != 'h') { set_detail("bad magic"); return CJS_E_NOT_BZIP_DATA; }
   int level = in[3] - '0';
-  if (level < 1 || level > 9) return CJS_E_NOT_BZIP_DATA;
-  uint32_t dbuf_size = 100000u * (uint32_t)level;
+  if (level < 1 || level > 9) { set_detail("level out of range"); return CJS_E_NOT_BZIP_DATA; }
+  int ndev = 0, dev0 = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipGetDevice(&dev0) != hipSuccess) return CJS_E_NO_DEVICE;
 
-  static const bool dbg_t = getenv("CJS_DEBUG") != nullptr;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto msd = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  const auto T0 = now();
-  hipStream_t s = nullptr;
-  uint8_t* d_in = nullptr; Cand* d_cand = nullptr; uint32_t* d_count = nullptr;
-  const uint32_t cand_cap = (uint32_t)(n / 64 + 1024);
-  int rc = 0;
-  std::vector<void*> to_free;
-  // scratch comes from the per-device buffer cache (kept between calls; cjs_trim() frees it)
-  auto dmalloc = [&](void** p, size_t bytes) { *p = DevPool::take(bytes); if (!*p) return (int)CJS_E_OUT_OF_MEMORY; to_free.push_back(*p); return 0; };
-  auto cleanup = [&]() { if (s) (void)hipStreamSynchronize(s); for (void* p : to_free) DevPool::give(p); if (s) (void)hipStreamDestroy(s); };
-  if (hipStreamCreate(&s) != hipSuccess) return CJS_E_HIP;
-  if (!rc) rc = dmalloc((void**)&d_in, n + 16);
-  if (!rc) rc = dmalloc((void**)&d_cand, sizeof(Cand) * cand_cap);
-  if (!rc) rc = dmalloc((void**)&d_count, 64);
-  if (!rc && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc && hipMemsetAsync(d_count, 0, 64, s) != hipSuccess) rc = CJS_E_HIP;
-  if (rc) { cleanup(); return rc; }
-  hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (uint64_t)n, d_cand, cand_cap, d_count);
-  uint32_t ncand = 0;
-  if (hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
-  if (ncand > cand_cap) { cleanup(); return CJS_E_DATA_ERROR; }
-  std::vector<Cand> cands(ncand);
-  if (ncand && hipMemcpy(cands.data(), d_cand, sizeof(Cand) * ncand, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return CJS_E_HIP; }
-  std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.bit < b.bit; });
-  if (ncand && hipMemcpy(d_cand, cands.data(), sizeof(Cand) * ncand, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return CJS_E_HIP; }
-
-  // speculative decode of every candidate (all stream levels of a multistream input must agree with the first one
-  // for the buffers; the reference asserts the same, :1858)
-  uint8_t* d_tt = nullptr; uint32_t* d_hist = nullptr; BlockOut* d_bo = nullptr;
-  if (!rc) rc = dmalloc((void**)&d_tt, (size_t)(ncand ? ncand : 1) * dbuf_size);
-  if (!rc) rc = dmalloc((void**)&d_hist, (size_t)(ncand ? ncand : 1) * 256 * 4);
-  if (!rc) rc = dmalloc((void**)&d_bo, sizeof(BlockOut) * (ncand ? ncand : 1));
-  if (rc) { cleanup(); return rc; }
-  std::vector<BlockOut> bos(ncand);
-  const auto T1 = now();
-  if (ncand) {
-    static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
-    static const bool v2 = getenv("CJS_DECODE_V2") != nullptr;      // the one-wave cooperative loop
-    if (v1) hipLaunchKernelGGL(bz_decode_block<1>, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
-    else if (v2) hipLaunchKernelGGL(bz_decode_block<2>, dim3(ncand), dim3(64), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_hist, d_bo);
-    else hipLaunchKernelGGL(bz_decode_block_pipe, dim3(ncand), dim3(128), 0, s, d_in, (uint64_t)n, d_cand, ncand, dbuf_size, d_tt, d_bo);
-    if (hipMemcpyAsync(bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
-    if (getenv("CJS_DEBUG")) {
-      uint64_t clk[8];
-      if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess)
-      {
-        if (v1 || v2) fprintf(stderr, "[cjs dec] candidate 0: header+selectors+lengths %.1f us, tables %.1f us, symbol loop %.1f us\n", (clk[1] - clk[0]) / 100.0, (clk[2] - clk[1]) / 100.0, (clk[3] - clk[2]) / 100.0);
-        else fprintf(stderr, "[cjs dec] candidate 0 (two-wave pipeline): %llu symbols; producer %.1f us, %llu rounds, waited for ring space %llu times; consumer %.1f us, %llu batches, found the ring empty %llu times\n",
-                     (unsigned long long)clk[7], clk[6] / 100.0, (unsigned long long)clk[5], (unsigned long long)clk[4], clk[2] / 100.0, (unsigned long long)clk[1], (unsigned long long)clk[0]);
-      }
+  DecJob J; J.in = in; J.n = n; J.mode = mode;
+  J.timing = getenv("CJS_DEBUG") != nullptr;
+  // The scratch rows are sized for the largest level any member stream can have: a multistream file may change level
+  // between members (:1787-1792), so every byte-aligned "BZh<d>" followed by a block or end-of-stream magic counts.
+  int max_level = level;
+  if (multistream && mode != 2) {
+    for (const uint8_t* p = in + 4; p + 10 <= in + n && (p = (const uint8_t*)memchr(p, 'B', (size_t)(in + n - 9 - p))) != nullptr; p++) {
+      if (p[1] != 'Z' || p[2] != 'h' || p[3] < '1' || p[3] > '9') continue;
+      uint64_t m = 0; for (int i = 0; i < 6; i++) m = (m << 8) | p[4 + i];
+      if ((m == MAGIC_BLOCK || m == MAGIC_END) && p[3] - '0' > max_level) max_level = p[3] - '0';
     }
   }
-  const auto T2 = now();
-  // chain walk (Bunzip.decode :1776-1794)
+  J.tt_stride = 100000u * (uint32_t)max_level;
+
+  // shares: contiguous byte ranges, one per requested device slot
+  uint32_t nsh = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->n_devices : 0;
+  if (const char* e = getenv("CJS_DEVICES")) nsh = (uint32_t)atoi(e);
+  if (nsh < 1 || mode == 2) nsh = 1;
+  if (nsh > 64) nsh = 64;
+  if ((size_t)nsh * 65536 > n) nsh = (uint32_t)(n / 65536 ? n / 65536 : 1);     // tiny inputs: one share
+  const uint64_t overlap = (uint64_t)J.tt_stride * 5 / 2 + 65536;               // one block at 20 bits per symbol + tables
+  std::vector<DecShare> sh(nsh);
+  for (uint32_t i = 0; i < nsh; i++) {
+    DecShare& S = sh[i];
+    S.device = nsh == 1 ? dev0 : (int)(i % (uint32_t)ndev);
+    S.lo = (uint64_t)n * i / nsh; S.hi = (uint64_t)n * (i + 1) / nsh;
+    S.up_lo = S.lo & ~(uint64_t)255;
+    S.up_hi = std::min<uint64_t>(n, S.hi + overlap);
+  }
+  if (mode == 2) {                                                             // one block: upload from its byte on
+    sh[0].lo = std::min<uint64_t>(at_bit >> 3, n); sh[0].hi = std::min<uint64_t>(n, sh[0].lo + 1);
+    sh[0].up_lo = sh[0].lo & ~(uint64_t)255; sh[0].up_hi = std::min<uint64_t>(n, sh[0].hi + overlap);
+  }
+  const auto T0 = std::chrono::steady_clock::now();
+  auto release_all = [&]() { for (auto& x : sh) x.release(); (void)hipSetDevice(dev0); };
+  int rc = for_each_share(sh, &J, dec_phase_a);
+  if (rc) { release_all(); return rc; }
+  const double ms_a = ms_since(T0);
+
+  // ---- chain walk over all shares' candidates (Bunzip.decode :1776-1794)
+  std::vector<uint64_t> cbit; std::vector<uint32_t> cshare, clocal;
+  for (uint32_t i = 0; i < nsh; i++) {
+    sh[i].cand_base = cbit.size();
+    for (size_t k = 0; k < sh[i].cands.size(); k++) { cbit.push_back(sh[i].cands[k].bit); cshare.push_back(i); clocal.push_back((uint32_t)k); }
+  }
   auto find = [&](uint64_t bit) -> long {
-    size_t lo = 0, hi = cands.size();
-    while (lo < hi) { size_t mid = (lo + hi) / 2; if (cands[mid].bit < bit) lo = mid + 1; else hi = mid; }
-    return (lo < cands.size() && cands[lo].bit == bit) ? (long)lo : -1;
+    const auto it = std::lower_bound(cbit.begin(), cbit.end(), bit);
+    return (it != cbit.end() && *it == bit) ? (long)(it - cbit.begin()) : -1;
   };
   auto read_bits = [&](uint64_t bit, int k) -> uint64_t { uint64_t v = 0; for (int i = 0; i < k; i++) { const uint64_t b = bit + i; v = (v << 1) | ((b >> 3) < n ? (in[b >> 3] >> (7 - (b & 7))) & 1u : 0u); } return v; };
-  std::vector<IbBlock> chain;
-  std::vector<uint64_t> chain_bits;
+  std::vector<uint32_t> chain_share;
+  uint32_t dbuf_size = 100000u * (uint32_t)level;                  // of the member stream being walked
+  auto take_block = [&](long ci, uint64_t bitpos) -> int {
+    const DecShare& S = sh[cshare[(size_t)ci]];
+    const BlockOut& bo = S.bos[clocal[(size_t)ci]];
+    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block at bit %llu: err %d count %u orig %u crc %08x end %llu\n", (unsigned long long)bitpos, bo.err, bo.count, bo.orig, bo.crc, (unsigned long long)bo.end_bit);
+    if (bo.err != CJS_E_OBSOLETE_INPUT && bo.orig > dbuf_size) { set_detail("initial position out of bounds"); return CJS_E_DATA_ERROR; }   // :1449-1450
+    if (bo.err) return bo.err;
+    if (bo.count > dbuf_size) return CJS_E_DATA_ERROR;             // decoded with the largest level's limit: this stream's is lower (:1647,1663)
+    IbBlock ib; ib.cand = clocal[(size_t)ci]; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
+    J.chain.push_back(ib); J.chain_bits.push_back(bitpos); chain_share.push_back(cshare[(size_t)ci]);
+    return 0;
+  };
   uint64_t pos = 32; uint32_t stream_crc = 0;
   if (mode == 2) {                                               // reader.seekBit(pos); _get_next_block() (:1803-1805)
     const long ci = find(at_bit);
     if (ci < 0) rc = CJS_E_NOT_BZIP_DATA;
-    else if (cands[ci].kind == 0) {
-      const BlockOut& bo = bos[ci];
-      if (bo.err) rc = bo.err;
-      else { IbBlock ib; ib.cand = (uint32_t)ci; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc; chain.push_back(ib); chain_bits.push_back(at_bit); }
-    }
+    else if (sh[cshare[(size_t)ci]].cands[clocal[(size_t)ci]].kind == 0) rc = take_block(ci, at_bit);
   } else for (;;) {
     if ((pos + 7) / 8 >= n) break;                               // inputStream.eof() (:1777)
     const long ci = find(pos);
     if (ci < 0) { rc = CJS_E_NOT_BZIP_DATA; break; }             // h !== WHOLEPI (:1438)
-    if (cands[ci].kind == 0) {
-      const BlockOut& bo = bos[ci];
-      if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block at bit %llu: err %d count %u orig %u crc %08x end %llu\n", (unsigned long long)pos, bo.err, bo.count, bo.orig, bo.crc, (unsigned long long)bo.end_bit);
-      if (bo.err) { rc = bo.err; break; }
+    const DecShare& S = sh[cshare[(size_t)ci]];
+    if (S.cands[clocal[(size_t)ci]].kind == 0) {
+      rc = take_block(ci, pos);
+      if (rc) break;
+      const BlockOut& bo = S.bos[clocal[(size_t)ci]];
       stream_crc = bo.crc ^ ((stream_crc << 1) | (stream_crc >> 31));
-      IbBlock ib; ib.cand = (uint32_t)ci; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
-      chain.push_back(ib); chain_bits.push_back(pos);
       pos = bo.end_bit;
     } else {
       const uint32_t target = (uint32_t)read_bits(pos + 48, 32);
       pos += 80;
       if ((pos + 7) / 8 > n) pos = (uint64_t)n * 8;
       if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] end of stream at bit %llu: stream crc %08x stored %08x\n", (unsigned long long)pos - 80, stream_crc, target);
-      if (mode == 0 && target != stream_crc) { rc = CJS_E_DATA_ERROR; break; }   // Bunzip.table ignores the stream crc (:1852)
+      if (mode == 0 && target != stream_crc) {                   // Bunzip.table ignores the stream crc (:1852)
+        set_detail("Bad stream CRC (got %x expected %x)", stream_crc, target);
+        rc = CJS_E_DATA_ERROR; break;
+      }
       const uint64_t byte = (pos + 7) / 8;
       if (multistream && byte < n) {                            // _start_bunzip again, byte aligned (:1787-1792)
-        if (byte + 4 > n || in[byte] != 'B' || in[byte + 1] != 'Z' || in[byte + 2] != 'h') { rc = CJS_E_NOT_BZIP_DATA; break; }
+        if (byte + 4 > n || in[byte] != 'B' || in[byte + 1] != 'Z' || in[byte + 2] != 'h') { set_detail("bad magic"); rc = CJS_E_NOT_BZIP_DATA; break; }
         const int lv = in[byte + 3] - '0';
-        if (lv < 1 || lv > 9) { rc = CJS_E_NOT_BZIP_DATA; break; }
-        if ((uint32_t)lv * 100000u != dbuf_size) { rc = CJS_E_UNSUPPORTED; break; }
+        if (lv < 1 || lv > 9) { set_detail("level out of range"); rc = CJS_E_NOT_BZIP_DATA; break; }
+        dbuf_size = 100000u * (uint32_t)lv;
+        if (dbuf_size > J.tt_stride) { rc = CJS_E_UNSUPPORTED; break; }        // cannot happen: the pre-scan saw this header
         pos = (byte + 4) * 8; stream_crc = 0;
       } else break;
     }
   }
-  if (rc) { cleanup(); return rc; }
-  const uint32_t nb = (uint32_t)chain.size();
-  if (nb == 0) { cleanup(); if (out) { *out = (uint8_t*)malloc(1); if (!*out) return CJS_E_OUT_OF_MEMORY; } return 0; }
-
-  // ---- inverse BWT for the chain's blocks
-  uint64_t M64 = 0;
-  for (auto& b : chain) { b.off = (uint32_t)M64; M64 += b.count; }
-  if (M64 >= 0xFFFFF000ull) { cleanup(); return CJS_E_UNSUPPORTED; }
-  const uint32_t M = (uint32_t)M64;
-  IbBlock* d_blocks = nullptr; uint32_t *d_key0 = nullptr, *d_key1 = nullptr, *d_val0 = nullptr, *d_val1 = nullptr, *d_dbuf = nullptr;
-  uint8_t* d_w = nullptr; uint32_t *d_snext = nullptr, *d_ssteps = nullptr, *d_srank = nullptr; int32_t* d_err = nullptr;
-  const uint32_t spl_stride = dbuf_size / SPL + 4;
-  BwtWork sw;
-  if (!rc) rc = dmalloc((void**)&d_blocks, sizeof(IbBlock) * nb);
-  if (!rc) rc = dmalloc((void**)&d_key0, 4 * (size_t)M + 64); if (!rc) rc = dmalloc((void**)&d_key1, 4 * (size_t)M + 64);
-  if (!rc) rc = dmalloc((void**)&d_val0, 4 * (size_t)M + 64); if (!rc) rc = dmalloc((void**)&d_val1, 4 * (size_t)M + 64);
-  if (!rc) rc = dmalloc((void**)&d_w, (size_t)M + 64);
-  if (!rc) rc = dmalloc((void**)&d_snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_ssteps, 4 * (size_t)nb * spl_stride);
-  if (!rc) rc = dmalloc((void**)&d_srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = dmalloc((void**)&d_err, 4 * (size_t)nb);
-  const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
-  if (!rc) rc = dmalloc((void**)&sw.hist, 256 * T * 4); if (!rc) rc = dmalloc((void**)&sw.bintot, 256 * 4);
-  sw.hist_tiles = (uint32_t)T; sw.bintot_segs = 1;
-  if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc && hipMemsetAsync(d_err, 0, 4 * (size_t)nb, s) != hipSuccess) rc = CJS_E_HIP;
-  if (rc) { cleanup(); return rc; }
-  d_dbuf = d_key1;   // reuse after the sort (see below)
-  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_tt, dbuf_size, d_blocks, d_key0, d_val0);
-  int cur = 0;
-  int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
-  rc = radix_passes_public<uint32_t>(s, sw, d_key0, d_val0, d_key1, d_val1, cur, M, 0, kbits);
-  if (rc) { cleanup(); return rc; }
-  uint32_t* skey = cur ? d_key1 : d_key0; uint32_t* sval = cur ? d_val1 : d_val0;
-  d_dbuf = cur ? d_key0 : d_key1;                                // the buffer the sort is not sitting in
-  (void)skey;
-  hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, d_tt, dbuf_size, d_blocks, sval, d_dbuf);
-  hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 0);
-  hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
-  hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_w, 0);
-  hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, d_blocks, d_err, d_w);
-  hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_w, d_blocks, (uint8_t*)nullptr, 0);
-  std::vector<int32_t> errs(nb);
-  if (hipMemcpyAsync(chain.data(), d_blocks, sizeof(IbBlock) * nb, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cleanup(); return CJS_E_HIP; }
-  for (uint32_t k = 0; k < nb; k++) if (errs[k] <= 0) { cleanup(); return CJS_E_DATA_ERROR; }    // cannot happen: the walk makes >= 1 step
-  uint64_t total = 0;
-  for (auto& b : chain) { b.out_off = total; total += b.out_len; }
-  uint8_t* d_out = nullptr; RleBlock* d_ranges = nullptr; uint32_t *d_nb = nullptr, *d_seg = nullptr, *d_crc = nullptr;
-  const uint32_t max_segs = (uint32_t)(((size_t)dbuf_size * 256 + 16383) / 16384 + 2);
-  uint32_t need_segs = 1;
-  for (auto& b : chain) { const uint32_t sg = (uint32_t)((b.out_len + 16383) / 16384 + 1); if (sg > need_segs) need_segs = sg; }
-  (void)max_segs;
-  if (!rc) rc = dmalloc((void**)&d_out, total + 64);
-  if (!rc) rc = dmalloc((void**)&d_ranges, sizeof(RleBlock) * nb);
-  if (!rc) rc = dmalloc((void**)&d_nb, 64);
-  if (!rc) rc = dmalloc((void**)&d_seg, 4 * (size_t)nb * need_segs);
-  if (!rc) rc = dmalloc((void**)&d_crc, 4 * (size_t)nb);
-  if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
-  if (rc) { cleanup(); return rc; }
-  hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_w, d_blocks, d_out, 1);
-  hipLaunchKernelGGL(ib_make_crc_ranges, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, d_ranges, d_nb);
-  rc = crc_ranges(s, d_out, d_ranges, d_nb, nb, need_segs, d_seg, d_crc);
-  std::vector<uint32_t> crcs(nb);
-  uint8_t* host = out ? (uint8_t*)malloc(total ? total : 1) : nullptr;
-  if (!rc && out && !host) rc = CJS_E_OUT_OF_MEMORY;
-  if (!rc && hipMemcpyAsync(crcs.data(), d_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc && out && total && hipMemcpyAsync(host, d_out, total, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc) for (uint32_t k = 0; k < nb; k++) if (crcs[k] != chain[k].crc) {                                    // Bad block CRC (:1756-1761)
-    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block %u: Bad block CRC (got %08x expected %08x) out_len %u\n", k, crcs[k], chain[k].crc, chain[k].out_len);
-    rc = CJS_E_DATA_ERROR; break;
+  if (rc) { release_all(); return rc; }
+  const size_t nb = J.chain.size();
+  if (nb == 0) { release_all(); if (out) { *out = (uint8_t*)malloc(1); if (!*out) return CJS_E_OUT_OF_MEMORY; } return 0; }
+  {  // the chain is increasing in bit position, so every share owns one contiguous run of it
+    size_t k = 0;
+    for (uint32_t i = 0; i < nsh; i++) { sh[i].c0 = k; while (k < nb && chain_share[k] == i) k++; sh[i].c1 = k; }
+    if (k != nb) { release_all(); return CJS_E_DATA_ERROR; }      // a chain that runs backwards: corrupt input
   }
-  const auto T3 = now();
-  cleanup();
-  if (dbg_t) fprintf(stderr, "[cjs dec] host phases: H2D + magic scan + candidate buffers %.2f ms, block decode %.2f ms, chain + inverse BWT + RLE1 + CRC + D2H %.2f ms, free %.2f ms\n", msd(T0, T1), msd(T1, T2), msd(T2, T3), msd(T3, now()));
-  if (rc) { free(host); return rc; }
+  const auto T1 = std::chrono::steady_clock::now();
+  rc = for_each_share(sh, &J, dec_phase_b);
+  if (rc) { release_all(); return rc; }
+  const double ms_b = ms_since(T1);
+  J.out_off.assign(nb + 1, 0);
+  for (size_t k = 0; k < nb; k++) J.out_off[k + 1] = J.out_off[k] + J.chain[k].out_len;
+  const uint64_t total = J.out_off[nb];
+  if (out) { J.host = (uint8_t*)malloc(total ? (size_t)total : 1); if (!J.host) { release_all(); return CJS_E_OUT_OF_MEMORY; } }
+  const auto T2 = std::chrono::steady_clock::now();
+  rc = for_each_share(sh, &J, dec_phase_c);
+  const double ms_c = ms_since(T2);
+  release_all();
+  if (J.timing) {
+    fprintf(stderr, "[cjs dec] %u share(s): upload + magic scan + block decode %.2f ms, inverse BWT + RLE1 lengths %.2f ms, RLE1 + CRC + D2H %.2f ms\n", nsh, ms_a, ms_b, ms_c);
+    for (uint32_t i = 0; i < nsh; i++) fprintf(stderr, "[cjs dec]   share %u (device %d): %zu candidates, blocks [%zu, %zu): %.2f / %.2f / %.2f ms\n", i, sh[i].device,
+                                               sh[i].cands.size(), sh[i].c0, sh[i].c1, sh[i].ms_a, sh[i].ms_b, sh[i].ms_c);
+  }
+  if (rc) { free(J.host); return rc; }
   if (tab_n) {
     *tab_n = (long)nb;
-    for (uint32_t k = 0; k < nb && (long)k < tab_cap; k++) { tab_pos[k] = chain_bits[k]; tab_size[k] = chain[k].out_len; }
+    for (size_t k = 0; k < nb && (long)k < tab_cap; k++) { tab_pos[k] = J.chain_bits[k]; tab_size[k] = J.chain[k].out_len; }
   }
-  if (out) { *out = host; *out_n = (size_t)total; }
+  if (out) { *out = J.host; *out_n = (size_t)total; }
   return 0;
 }
 
 extern "C" int cjs_bzip2_decompress(const uint8_t* in, size_t n, int multistream, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
   if (!out || !out_n) return CJS_E_INVALID_ARG;
+  CJS_GUARD_BEGIN
   return bunzip_core(in, n, multistream, 0, 0, out, out_n, nullptr, nullptr, 0, nullptr, opts);
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 extern "C" int cjs_bzip2_decompress_block(const uint8_t* in, size_t n, uint64_t bitpos, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
   if (!out || !out_n) return CJS_E_INVALID_ARG;
+  CJS_GUARD_BEGIN
   return bunzip_core(in, n, 0, 2, bitpos, out, out_n, nullptr, nullptr, 0, nullptr, opts);
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 extern "C" long cjs_bzip2_table(const uint8_t* in, size_t n, int multistream, uint64_t* bitpos, uint32_t* size, long cap, const cjs_opts* opts) {
+  CJS_GUARD_BEGIN
   long nbk = 0;
   const int rc = bunzip_core(in, n, multistream, 1, 0, nullptr, nullptr, bitpos, size, cap, &nbk, opts);
   return rc ? (long)rc : nbk;
+  CJS_GUARD_END((long)CJS_E_OUT_OF_MEMORY, (long)CJS_E_HIP)
 }

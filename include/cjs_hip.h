@@ -51,9 +51,12 @@ typedef struct cjs_opts {
   uint32_t struct_size;   /* sizeof(cjs_opts) */
   int32_t device;         /* HIP device ordinal; -1 = current device */
   uint32_t n_devices;     /* host-buffer entry points: shard blocks over this many GPUs (0/1 = one) */
-  uint32_t flags;
+  uint32_t flags;         /* CJS_FLAG_* */
   cjs_stats *stats;       /* optional out */
 } cjs_opts;
+/* cjs_bwtc_compress: the input came from a stream without a known size, so the header carries varint(0) instead of
+ * varint(size+1) (Util.compressFileHelper, J/BWTC_joined_.js:529-543) */
+#define CJS_FLAG_SIZE_UNKNOWN 1u
 
 /* ---- host-buffer entry points (what the JS fronts bind).
  * cjs_bzip2_compress   replaces Bzip2.compressFile    J/Bzip2_joined_.js:2199-2249
@@ -76,6 +79,11 @@ void cjs_free(void *p);
  * (environment CJS_NO_CTX_CACHE=1: never keep it). */
 void cjs_trim(void);
 const char *cjs_strerror(int code);
+/* Detail text of the most recent FAILED call on the calling thread, "" if it had none: the reference's optDetail
+ * of _throw(status, optDetail) (J/Bzip2_joined_.js:1385-1391), e.g. "bad magic", "level out of range",
+ * "initial position out of bounds", "Bad block CRC (got 1a2b3c4d expected 5e6f7081)", "Bad stream CRC (got .. expected ..)"
+ * (:1413,1417,1450,1757,1783).  A front appends it to cjs_strerror(code) after ": ".  Valid until the thread's next call. */
+const char *cjs_last_error_detail(void);
 int cjs_device_count(void);
 const char *cjs_version(void);
 
@@ -117,6 +125,13 @@ int cjs_stage_mtf(const uint8_t *U, const uint8_t *blocks, size_t n, int block_l
 /* Huffman tables + selectors (J/Bzip2_joined_.js:1989-2054,2147-2163) for one symbol stream */
 int cjs_stage_huff(const uint16_t *A, uint32_t npos, uint32_t alphabet, uint8_t *selectors, uint8_t *lengths /* 6*258 */,
                    uint32_t *ngroups, const cjs_opts *opts);
+
+/* Serial entropy stage of BWTC.decompressFile (J/BWTC_joined_.js:1827-1913): range decoder + adaptive model + RLE2 + MTF
+ * inverse, i.e. everything before BWT.unbwtransform.  Host logic only (the one entry point that needs no device; the chain
+ * is serial by the format).  *cols receives the BWT columns of all non-empty blocks back to back (malloc'd, cjs_free);
+ * lens[k] / pidx[k] for up to cap blocks; *level = the stream's level.  Returns the number of blocks or a negative code. */
+long cjs_stage_bwtc_entropy_decode(const uint8_t *in, size_t n, uint8_t **cols, size_t *cols_n, uint32_t *lens, uint32_t *pidx,
+                                   long cap, int *level);
 
 #ifdef __cplusplus
 }

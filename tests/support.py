@@ -209,6 +209,8 @@ class HipLib(_StreamLib):
             "cjs_stage_rle1": [V, S, I, V, S, V, V, V, ctypes.c_long, ctypes.POINTER(ctypes.c_long), V],
             "cjs_stage_mtf": [V, V, S, I, V, V, V, V, V],
             "cjs_stage_huff": [V, ctypes.c_uint32, ctypes.c_uint32, V, V, V, V],
+            "cjs_stage_bwtc_entropy_decode": [u8p, S, PP, PS, V, V, ctypes.c_long, ctypes.POINTER(I)],
+            "cjs_last_error_detail": [],
         }
         self.missing = []
         for name, args in sigs.items():
@@ -220,6 +222,10 @@ class HipLib(_StreamLib):
             fn.restype = I
         L.cjs_strerror.restype = ctypes.c_char_p
         L.cjs_version.restype = ctypes.c_char_p
+        if hasattr(L, "cjs_last_error_detail"):
+            L.cjs_last_error_detail.restype = ctypes.c_char_p
+        if hasattr(L, "cjs_stage_bwtc_entropy_decode"):
+            L.cjs_stage_bwtc_entropy_decode.restype = ctypes.c_long
         L.cjs_free.restype = None
         L.cjs_trim.argtypes = []
         L.cjs_trim.restype = None
@@ -252,6 +258,28 @@ class HipLib(_StreamLib):
         if n < 0:
             return n, None
         return 0, list(zip(pos[:n].tolist(), size[:n].tolist()))
+
+    def last_error_detail(self):
+        return self.L.cjs_last_error_detail().decode()
+
+    def stage_bwtc_entropy_decode(self, data, cap=1 << 16):
+        """(rc or number of blocks, level, [(BWT column bytes, pidx)])  -- host logic, runs without a GPU"""
+        data = as_u8(data)
+        keep = data if data.size else np.zeros(1, dtype=np.uint8)
+        cols, cols_n, level = u8p(), ctypes.c_size_t(0), ctypes.c_int(0)
+        lens = np.zeros(cap, dtype=np.uint32)
+        pidx = np.zeros(cap, dtype=np.uint32)
+        nb = self.L.cjs_stage_bwtc_entropy_decode(keep.ctypes.data_as(u8p), data.size, ctypes.byref(cols), ctypes.byref(cols_n),
+                                                  lens.ctypes.data, pidx.ctypes.data, cap, ctypes.byref(level))
+        if nb < 0:
+            return nb, 0, None
+        flat = np.ctypeslib.as_array(cols, shape=(max(cols_n.value, 1),))[: cols_n.value].copy() if cols_n.value else np.empty(0, np.uint8)
+        self.L.cjs_free(cols)
+        out, off = [], 0
+        for k in range(min(nb, cap)):
+            out.append((flat[off: off + int(lens[k])], int(pidx[k])))
+            off += int(lens[k])
+        return nb, level.value, out
 
     def stage_bwt(self, data, block_len, cyclic):
         data = as_u8(data)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage: tools/gpu_ab.sh "<ENV=val ...>" ["<ENV=val ...>" ...] -- A/B of bench stage times under different env settings
+# (each arm is checked bit-exact against the reference golden by bench.py's verify, outside the timed region)
 cd "$GRAFT_REPO_ROOT" || exit 1
 for e in "$@"; do
   echo "== $e"
-  env $(echo $e | sed "s#=ab/#=$GRAFT_REPO_ROOT/ab/#") timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify 2>&1 | grep -o '"ms_per_step": [0-9.]*\|"stage_ms_per_step": {[^}]*}' || exit 1
+  env $(echo $e | sed "s#=ab/#=$GRAFT_REPO_ROOT/ab/#") timeout -k 10 200 python bench.py --steps ${AB_STEPS:-3} --warmup 1 --no-cpu-baseline 2>gpurun_out/ab_last.err | grep -o '"ms_per_step": [0-9.]*\|"stage_ms_per_step": {[^}]*}\|"bit_exact_vs_reference_js": [a-z]*\|"bwt_rounds": [0-9]*' || { tail -5 gpurun_out/ab_last.err; exit 1; }
 done

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Timeline of the LAST bench step from a rocprofv3 --kernel-trace CSV: kernels in launch order with their
+durations (us) and the gap to the previous kernel, one line per suffix-sort round."""
+import csv
+import sys
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
+def short(n):
+    n = n.split('(')[0].replace('cjs::', '').replace('void ', '')
+    return n.split('<')[0] + ('<' + n.split('<')[1][:12] if '<' in n else '')
+names = [short(r['Kernel_Name']) for r in rows]
+# last step = from the last rle_tile_summary on
+start = max(i for i, n in enumerate(names) if n.startswith('rle_tile_summary'))
+line, t_prev, total, gaps = [], None, 0.0, 0.0
+for r, n in list(zip(rows, names))[start:]:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    d = (e - s) / 1e3
+    gap = (s - t_prev) / 1e3 if t_prev is not None else 0.0
+    t_prev = e
+    total += d; gaps += max(gap, 0.0)
+    if n.startswith('bwt_gather_keys') or n.startswith('mtf_head_tiles') and line and not line[-1].startswith('mtf'):
+        print('  '.join(line)); line = []
+    line.append('%s %.0f%s' % (n.replace('bwt_', '').replace('rs_', 'r:'), d, ('(+%.0f)' % gap) if gap > 8 else ''))
+print('  '.join(line))
+print('last step: kernel time %.2f ms, gaps %.2f ms' % (total / 1e3, gaps / 1e3))
