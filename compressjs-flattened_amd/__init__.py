@@ -63,6 +63,7 @@ def load_library():
     L.cjs_strerror.argtypes = [I]
     L.cjs_strerror.restype = ctypes.c_char_p
     L.cjs_version.restype = ctypes.c_char_p
+    L.cjs_last_error_detail.restype = ctypes.c_char_p
     L.cjs_device_count.restype = I
     L.cjs_ctx_create.argtypes = [ctypes.POINTER(V), I, S, I]
     L.cjs_ctx_create_sharded.argtypes = [ctypes.POINTER(V), I, S, ctypes.c_long, I]
@@ -77,7 +78,9 @@ def load_library():
 
 def _check(rc):
     if rc != 0:
-        raise CjsError(rc, load_library().cjs_strerror(rc).decode())
+        L = load_library()
+        detail = L.cjs_last_error_detail().decode()          # the reference's optDetail (J/Bzip2_joined_.js:1385-1391)
+        raise CjsError(rc, L.cjs_strerror(rc).decode() + (": " + detail if detail else ""))
 
 
 def _coerce_input(data):
@@ -103,8 +106,11 @@ class Bzip2:
 
     @staticmethod
     def compressFile(input, output=None, props=None):
-        level = props if isinstance(props, int) and not isinstance(props, bool) else 9   # Q17
-        if level < 1 or level > 9:
+        # Q17: typeof props === 'number' -> the level, anything else -> 9 (5.0 is the number 5 in JavaScript)
+        level = props if isinstance(props, (int, float)) and not isinstance(props, bool) else 9
+        if isinstance(level, float) and level == int(level):
+            level = int(level)
+        if level < 1 or level > 9 or not isinstance(level, int):      # (a fractional level is meaningless; the reference does not guard it)
             raise CjsError(-20, "Invalid block size multiplier")
         res = _stream_call(load_library().cjs_bzip2_compress, input, level)
         return _deliver(res, output)
@@ -120,7 +126,7 @@ class BWTC:
 
     @staticmethod
     def compressFile(input, output=None, props=None):
-        level = props if isinstance(props, int) and not isinstance(props, bool) and 1 <= props <= 9 else 9   # W2
+        level = int(props) if isinstance(props, (int, float)) and not isinstance(props, bool) and 1 <= props <= 9 and props == int(props) else 9   # W2
         return _deliver(_stream_call(load_library().cjs_bwtc_compress, input, level), output)
 
     @staticmethod

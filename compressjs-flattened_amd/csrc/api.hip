@@ -118,6 +118,7 @@ int select_device(const cjs_opts* opts) {
 }  // namespace cjs
 
 extern "C" int cjs_stage_bwt(const uint8_t* in, size_t n, int block_len, int cyclic, uint8_t* out, int32_t* pidx, const cjs_opts* opts) {
+  CJS_GUARD_BEGIN
   CJS_TRY(select_device(opts));
   if (n == 0) return 0;
   if (block_len <= 0) return CJS_E_INVALID_ARG;
@@ -140,14 +141,16 @@ extern "C" int cjs_stage_bwt(const uint8_t* in, size_t n, int block_len, int cyc
   if (!rc && hipMemcpyAsync(pidx, d_p, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
   if (s) (void)hipStreamDestroy(s);
-  if (w.h_counters) (void)hipHostFree(w.h_counters);
+  w.release_host();
   arena.destroy();
   return rc;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 
 extern "C" int cjs_stage_rle1(const uint8_t* in, size_t n, int level, uint8_t* blocks, size_t blocks_cap,
                               uint32_t* block_len, uint32_t* block_crc, uint64_t* block_start, long cap_blocks, long* nblocks,
                               const cjs_opts* opts) {
+  CJS_GUARD_BEGIN
   CJS_TRY(select_device(opts));
   if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;
   const uint32_t cap = (uint32_t)level * 100000u - 19u;
@@ -182,5 +185,6 @@ extern "C" int cjs_stage_rle1(const uint8_t* in, size_t n, int level, uint8_t* b
   w.release();
   arena.destroy();
   return rc;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 

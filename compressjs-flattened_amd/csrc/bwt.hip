@@ -99,16 +99,16 @@ __device__ __forceinline__ uint64_t gen_key(const GenSrc& gs, const SegGeom& sg,
 }
 
 // Per-tile digit counts, tile-major: hist[tile * 256 + digit] (one coalesced 1 KB row per workgroup; the digit-major
-// layout of round 1 cost a 64-byte memory transaction per 4-byte counter on both sides).  Text digits are heavily
-// skewed (a few byte values take most of the counts), so every wave counts into 8 sub-histograms picked by lane & 7:
-// the same-address serialisation of the LDS atomics drops 8-fold.
+// layout of round 1 cost a 64-byte memory transaction per 4-byte counter on both sides).  One sub-histogram per wave.
+// (Eight sub-histograms per wave picked by lane & 7 against the same-address serialisation of skewed text digits were
+// measured slower, 283 vs 235 us per 100 M keys: zeroing and folding 32 KB of LDS per tile costs more than it saves.)
 template <typename K, bool GEN>
 __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGeom sg, GenSrc gs, int shift,
                                                uint32_t* __restrict__ hist, uint32_t T) {
-  __shared__ uint32_t h[4][8][256];
+  __shared__ uint32_t h[4][256];
   __shared__ __attribute__((aligned(16))) uint8_t tb[GEN ? RS_TILE + GEN_PAD + 16 : 16];
-  const int tid = threadIdx.x, w = tid >> 6, sub = tid & 7;
-  for (int i = tid; i < 4 * 8 * 256; i += 256) (&h[0][0][0])[i] = 0;
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
   const uint32_t tile = blockIdx.x;
   const TileRef t = tile_ref(sg, tile);
   uint32_t tb0 = 0;
@@ -119,14 +119,11 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
     const uint32_t loc = (uint32_t)it * 256 + tid;
     if (loc < t.nvalid) {
       const uint64_t k = GEN ? gen_key(gs, sg, t, tb, tb0, loc) : (uint64_t)keys[t.base + loc];
-      atomicAdd(&h[w][sub][(uint32_t)(k >> shift) & 255u], 1u);
+      atomicAdd(&h[w][(uint32_t)(k >> shift) & 255u], 1u);
     }
   }
   __syncthreads();
-  uint32_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 32; i++) c += (&h[0][0][0])[i * 256 + tid];
-  hist[(size_t)tile * 256 + tid] = c;
+  hist[(size_t)tile * 256 + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
 }
 
 // one workgroup per segment: exclusive scan over the segment's tiles of every digit's count (thread = digit; the rows are
@@ -279,6 +276,30 @@ __global__ __launch_bounds__(256) void bwt_init_keys(const uint8_t* __restrict__
   }
 }
 
+// Two-sweep scheduling of the round-1 rank scatter: a block's 3.6 MB rank region does not survive in a 4 MiB L2 next to
+// the streamed arrays (PMC: ~64 B of memory traffic per 4-byte store), so blocks are dealt to the XCDs round-robin
+// (workgroup 8j+x -> XCD x) and each XCD walks the tiles of one block twice, storing first the ranks of the lower half
+// of the block's text positions, then the upper half (1.8 MB per sweep).  `slots` tile slots per (block, sweep).
+// PMC: WRITE_SIZE of the kernel 6.66 -> 2.67 GB per 100 MB step; its time 1.64 -> 1.35 ms (the second sweep re-reads and
+// re-derives the group structure).  The same scheduling applied to the gather / scatter of rounds >= 2 over the compacted
+// arrays (per-block start table from a binary search) was measured SLOWER (gather 0.84 -> 1.07 ms, scatter 1.24 -> 1.84 ms
+// in round 2) and is not kept.
+struct HalfMap { uint32_t halves, slots, stride; };
+__device__ __forceinline__ bool half_map(const HalfMap& hm, uint32_t nb, uint32_t A, uint32_t T, uint32_t& tile, uint32_t& half) {
+  half = 0;
+  if (hm.halves <= 1) { tile = xcd_tile(blockIdx.x, T); return tile < T; }
+  const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = 2u * hm.slots;
+  const uint32_t bi = j / per, r = j - bi * per, blk = x + 8u * bi;
+  half = r / hm.slots;
+  if (blk >= nb) return false;
+  const uint64_t s0 = (uint64_t)blk * hm.stride, s1 = blk + 1 == nb ? (uint64_t)A : (uint64_t)(blk + 1) * hm.stride;
+  const uint32_t ft = (uint32_t)((s0 + RS_TILE - 1) / RS_TILE);       // a tile belongs to the block of its first element
+  uint32_t fe = (uint32_t)((s1 + RS_TILE - 1) / RS_TILE);
+  if (fe > T) fe = T;
+  tile = ft + (r - half * hm.slots);
+  return tile < fe;
+}
+
 // round r>=1 keys: (group ordinal, rank of suffix i+h)
 __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint32_t A, uint32_t h, const uint32_t* __restrict__ R,
                                                        const uint32_t* __restrict__ val, const uint32_t* __restrict__ pos,
@@ -359,12 +380,7 @@ __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ ti
 // regroup: new ranks -> R (scattered 4-byte stores), singletons -> SA, survivors compacted into the next
 // active arrays.  Fully lane-striped: the per-element prefix quantities come from 4096-bit masks
 // (wave ballots) + a 64-word scan, so every global access of a wave touches consecutive addresses.
-// Two-sweep rank scatter (round 1, `halves` = 2): the scattered 4-byte stores into a block's 3.6 MB rank region do not
-// survive in a 4 MiB L2 next to the streamed arrays (PMC: ~43 B written per store).  Each XCD therefore walks the tiles
-// of one block twice, storing first the ranks of the lower half of the block's text positions, then the upper half
-// (1.8 MB of destination per sweep); everything else is written by the first sweep only.  Blocks are dealt to the XCDs
-// round-robin (workgroup 8j+x -> XCD x), HALF_SLOTS tile slots per (block, sweep).
-struct HalfMap { uint32_t halves, slots, stride; };
+// `hm_`: two-sweep scheduling of the scattered rank stores (see HalfMap); everything but the ranks is written by sweep 0.
 template <bool FIRST, bool PACKED>      // FIRST: round 1 - slot a is sorted position a, and there is no previous grouping
 __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                  const uint32_t* __restrict__ pos, uint32_t A, Geom g,
@@ -374,20 +390,8 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
-  uint32_t tile, half = 0;
-  if (hm_.halves <= 1) tile = xcd_tile(blockIdx.x, T);
-  else {
-    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = 2u * hm_.slots;
-    const uint32_t bi = j / per, r = j - bi * per, blk = x + 8u * bi;
-    half = r / hm_.slots;
-    if (blk >= g.nb) return;
-    const uint32_t ft = (uint32_t)(((uint64_t)blk * hm_.stride + RS_TILE - 1) / RS_TILE);
-    uint32_t fe = (uint32_t)(((uint64_t)(blk + 1) * hm_.stride + RS_TILE - 1) / RS_TILE);
-    if (fe > T || blk + 1 == g.nb) fe = T;
-    tile = ft + (r - half * hm_.slots);
-    if (tile >= fe) return;
-  }
-  if (tile >= T) return;
+  uint32_t tile, half;
+  if (!half_map(hm_, g.nb, A, T, tile, half)) return;
   const uint32_t hsplit = hm_.stride >> 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint64_t base = (uint64_t)tile * RS_TILE;
@@ -1040,6 +1044,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   uint32_t A = M, h = (uint32_t)nsym, rounds = 0;
   w.no_large_groups = false;
   int bits = nsym * sym_bits + (segmented ? 0 : blk_bits);
+  const bool sweeps = env_halves >= 2 && nb >= 8;      // two-sweep scheduling of the round-1 rank scatter (see HalfMap)
   for (;;) {
     if (rounds == 0) {
       if (packed) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
@@ -1052,7 +1057,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     if (rounds == 0) {
       HalfMap hm{1u, 0u, stride};
       uint32_t grid = xcd_grid(T);
-      if (env_halves >= 2 && nb >= 8) {        // two destination sweeps per block (see bwt_apply)
+      if (sweeps) {
         hm.halves = 2; hm.slots = (stride + RS_TILE - 1) / RS_TILE + 1;
         grid = 8u * ((nb + 7u) / 8u) * 2u * hm.slots;
       }

@@ -13,8 +13,11 @@
 #include "mtf.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace cjs {
@@ -428,19 +431,146 @@ void logdist(HostCoder& c, int block_size, uint32_t d) {                        
 
 }  // namespace
 
+// One batch of consecutive blocks: BWT -> MTF/RLE2 -> model evaluation on one GPU (worker thread), leaving the per-block
+// step lists in HBM until the coder has consumed them.  Blocks are dealt to the device slots in contiguous ranges
+// (cjs_opts.n_devices / CJS_DEVICES; SURVEY §8e "BWTC compress": replicable stages x N, serial tail x 1); the first
+// batch of the job is small so that the coder starts early, and at most two batches per slot are alive.
+namespace {
+
+constexpr uint32_t BWTC_FIRST_BATCH = 8, BWTC_MAX_BATCH = 512;
+
+struct BwtcBatch {
+  int slot = 0, device = 0, seq = 0;          // seq: order of the batch inside its slot
+  uint32_t first = 0, count = 0;
+  int rc = 0;
+  bool done = false;
+  Arena arena; BwtWork bw;
+  hipStream_t s = nullptr, cs = nullptr;      // work stream, copy stream (step lists -> pinned host buffers)
+  hipEvent_t cev[2] = {nullptr, nullptr};
+  uint64_t* d_steps = nullptr; size_t step_stride = 0;
+  std::vector<uint32_t> pidx, asz, nsteps; std::vector<uint8_t> alist;
+  double ms = 0;
+  void release() {
+    if (hipSetDevice(device) != hipSuccess) return;
+    if (s) (void)hipStreamSynchronize(s);
+    if (cs) (void)hipStreamSynchronize(cs);
+    for (int q = 0; q < 2; q++) if (cev[q]) { (void)hipEventDestroy(cev[q]); cev[q] = nullptr; }
+    if (cs) { (void)hipStreamDestroy(cs); cs = nullptr; }
+    if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+    bw.release_host();
+    arena.destroy();
+  }
+};
+
+struct BwtcJob {
+  const uint8_t* in = nullptr; size_t n = 0;
+  uint32_t bs = 0, nb = 0, n_last = 0; bool fast = false;
+  std::vector<BwtcBatch> batches;
+  std::mutex mu; std::condition_variable cv;
+  std::vector<int> live, next_seq;            // per slot: batches alive, next batch allowed to start
+  bool abort = false;
+};
+
+void bwtc_batch_worker(BwtcJob* J, BwtcBatch* B) {
+  {
+    std::unique_lock<std::mutex> lk(J->mu);
+    J->cv.wait(lk, [&] { return J->abort || (J->next_seq[B->slot] == B->seq && J->live[B->slot] < 2); });
+    if (J->abort) { B->rc = CJS_E_HIP; B->done = true; J->next_seq[B->slot]++; J->cv.notify_all(); return; }
+    J->live[B->slot]++; J->next_seq[B->slot]++;
+    J->cv.notify_all();
+  }
+  const auto T0 = std::chrono::steady_clock::now();
+  int rc = 0;
+  const uint32_t bs = J->bs, cnt = B->count;
+  const bool last = B->first + cnt == J->nb;
+  const uint32_t n_last = last ? J->n_last : bs;
+  const size_t elems = (size_t)cnt * bs, nbytes = (size_t)(cnt - 1) * bs + n_last;
+  const size_t a_stride = MtfWork::a_stride_for(bs);
+  B->step_stride = 2 * a_stride;
+  MtfWork mw;
+  uint8_t *d_T = nullptr, *d_U = nullptr; uint32_t *d_pidx = nullptr, *d_len = nullptr, *d_nsteps = nullptr;
+  if (hipSetDevice(B->device) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) rc = B->arena.init(BwtWork::bytes_needed(elems) + MtfWork::bytes_needed(cnt, bs) + 2 * (elems + 512) + 8 * (size_t)cnt * B->step_stride + 16 * (size_t)cnt + 65536);
+  if (!rc) rc = B->bw.carve(B->arena, elems);
+  if (!rc) rc = mw.carve(B->arena, cnt, bs);
+  if (!rc) {
+    d_T = B->arena.take<uint8_t>(elems); d_U = B->arena.take<uint8_t>(elems);
+    d_pidx = B->arena.take<uint32_t>(cnt); d_len = B->arena.take<uint32_t>(cnt); d_nsteps = B->arena.take<uint32_t>(cnt);
+    B->d_steps = B->arena.take<uint64_t>((size_t)cnt * B->step_stride);
+    if (!B->d_steps) rc = CJS_E_OUT_OF_MEMORY;
+  }
+  if (!rc && B->slot == 0 && B->seq == 0 && J->batches.size() > 1) {   // the batch the coder is waiting for goes ahead of the others' kernels
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&B->s, hipStreamDefault, greatest) != hipSuccess) B->s = nullptr;
+  }
+  if (!rc && ((!B->s && hipStreamCreate(&B->s) != hipSuccess) || hipStreamCreate(&B->cs) != hipSuccess ||
+              hipEventCreateWithFlags(&B->cev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&B->cev[1], hipEventDisableTiming) != hipSuccess)) rc = CJS_E_HIP;
+  std::vector<uint32_t> lens(cnt, bs); lens[cnt - 1] = n_last;
+  hipStream_t s = B->s;
+  if (!rc && hipMemcpyAsync(d_T, J->in + (size_t)B->first * bs, nbytes, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpyAsync(d_len, lens.data(), 4 * (size_t)cnt, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc) rc = bwt_run(s, B->bw, d_T, cnt, bs, n_last, false, d_U, d_pidx, nullptr);
+  if (!rc) rc = mtf_run(s, mw, d_U, cnt, d_len);
+  if (!rc) {
+    if (J->fast) hipLaunchKernelGGL(bwtc_defsum, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps);
+    else if (getenv("CJS_BWTC_SERIAL_MODEL")) hipLaunchKernelGGL(bwtc_fenwick, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps);
+    else hipLaunchKernelGGL(bwtc_fenwick_par, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps, getenv("CJS_BWTC_FORCE_SERIAL") ? atoi(getenv("CJS_BWTC_FORCE_SERIAL")) : 0);
+    if (hipGetLastError() != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && !J->fast && getenv("CJS_BWTC_CHECK")) {               // debug: the one-symbol-at-a-time kernel must give the same steps
+      uint64_t* d_ref = nullptr; uint32_t* d_nref = nullptr;
+      if (hipMalloc((void**)&d_ref, 8 * (size_t)cnt * B->step_stride) == hipSuccess && hipMalloc((void**)&d_nref, 4 * (size_t)cnt) == hipSuccess) {
+        hipLaunchKernelGGL(bwtc_fenwick, dim3(cnt), dim3(64), 0, s, mw.b, d_ref, B->step_stride, d_nref);
+        std::vector<uint32_t> na(cnt), nr(cnt);
+        (void)hipMemcpyAsync(na.data(), d_nsteps, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(nr.data(), d_nref, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        for (uint32_t k = 0; k < cnt; k++) {
+          const uint32_t m = na[k] < nr[k] ? na[k] : nr[k];
+          std::vector<uint64_t> x(m), r(m);
+          if (m) { (void)hipMemcpy(x.data(), B->d_steps + (size_t)k * B->step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); (void)hipMemcpy(r.data(), d_ref + (size_t)k * B->step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); }
+          uint32_t i = 0; while (i < m && x[i] == r[i]) i++;
+          if (i < m || na[k] != nr[k]) { fprintf(stderr, "[cjs bwtc check] block %u: steps %u vs %u, first difference at %u\n", B->first + k, na[k], nr[k], i); break; }
+        }
+      }
+      if (d_ref) (void)hipFree(d_ref);
+      if (d_nref) (void)hipFree(d_nref);
+    }
+  }
+  B->pidx.resize(cnt); B->asz.resize(cnt); B->nsteps.resize(cnt); B->alist.resize((size_t)cnt * 256);
+  if (!rc && hipMemcpyAsync(B->pidx.data(), d_pidx, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpyAsync(B->asz.data(), mw.b.asz, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpyAsync(B->nsteps.data(), d_nsteps, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipMemcpyAsync(B->alist.data(), mw.b.alist, (size_t)cnt * 256, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
+  B->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count();
+  std::lock_guard<std::mutex> lk(J->mu);
+  B->rc = rc; B->done = true;
+  if (rc) J->abort = true;
+  J->cv.notify_all();
+}
+
+}  // namespace
+
 extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
   if (!out || !out_n) return CJS_E_INVALID_ARG;
   *out = nullptr; *out_n = 0;
+  clear_detail();
+  CJS_GUARD_BEGIN
   CJS_TRY(select_device(opts));
   if (level < 1 || level > 9) level = 9;                             // J/BWTC_joined_.js:1702-1705
-  const bool fast = level <= 5;
-  const uint32_t bs = (uint32_t)level * 100000u;
-  const uint32_t nb = (uint32_t)((n + bs - 1) / bs);
+  int ndev = 0, dev0 = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipGetDevice(&dev0) != hipSuccess) return CJS_E_NO_DEVICE;
+  BwtcJob J;
+  J.in = in; J.n = n; J.fast = level <= 5; J.bs = (uint32_t)level * 100000u;
+  J.nb = (uint32_t)((n + J.bs - 1) / J.bs);
+  J.n_last = J.nb ? (uint32_t)(n - (size_t)(J.nb - 1) * J.bs) : 0;
+  const uint32_t bs = J.bs, nb = J.nb;
   std::vector<uint8_t> o;
   o.reserve(n / 3 + 64);
   o.push_back('b'); o.push_back('w'); o.push_back('t'); o.push_back('c');
   uint8_t vb[12]; int nv = 0;                                        // writeUnsignedNumber(size+1) :605-620
-  { uint64_t v = (uint64_t)n + 1; do { vb[nv++] = (uint8_t)(v & 0x7F); v >>= 7; } while (v); vb[0] |= 0x80; }
+  const bool size_unknown = opts && opts->struct_size >= sizeof(cjs_opts) && (opts->flags & CJS_FLAG_SIZE_UNKNOWN);
+  { uint64_t v = size_unknown ? 0 : (uint64_t)n + 1; do { vb[nv++] = (uint8_t)(v & 0x7F); v >>= 7; } while (v); vb[0] |= 0x80; }   // W1: a stream without .size gives varint(0)
   for (int i = nv - 1; i >= 1; i--) o.push_back(vb[i]);
   HostCoder coder(o);
   coder.start(vb[0], 1);                                             // :1700 (the last varint byte is the coder's first byte)
@@ -448,94 +578,84 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
   int rc = 0;
   const auto T0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  double ms_coder = 0, ms_stall = 0, ms_first = 0;
   if (nb) {
-    const uint32_t n_last = (uint32_t)(n - (size_t)(nb - 1) * bs);
-    Arena arena;
-    const size_t elems = (size_t)nb * bs;
-    const size_t a_stride = MtfWork::a_stride_for(bs), step_stride = 2 * a_stride;
-    CJS_TRY(arena.init(BwtWork::bytes_needed(elems) + MtfWork::bytes_needed(nb, bs) + 2 * (elems + 512) + 8 * (size_t)nb * step_stride +
-                       16 * (size_t)nb + 65536));
-    BwtWork bw; MtfWork mw;
-    rc = bw.carve(arena, elems);
-    if (!rc) rc = mw.carve(arena, nb, bs);
-    uint8_t* d_T = arena.take<uint8_t>(elems);
-    uint8_t* d_U = arena.take<uint8_t>(elems);
-    uint32_t* d_pidx = arena.take<uint32_t>(nb);
-    uint32_t* d_len = arena.take<uint32_t>(nb);
-    uint32_t* d_nsteps = arena.take<uint32_t>(nb);
-    uint64_t* d_steps = arena.take<uint64_t>((size_t)nb * step_stride);
-    if (!rc && !d_steps) rc = CJS_E_OUT_OF_MEMORY;
-    hipStream_t s = nullptr;
-    if (!rc && hipStreamCreate(&s) != hipSuccess) rc = CJS_E_HIP;
-    std::vector<uint32_t> lens(nb, bs); lens[nb - 1] = n_last;
-    if (!rc && hipMemcpyAsync(d_T, in, n, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && hipMemcpyAsync(d_len, lens.data(), 4 * (size_t)nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc) rc = bwt_run(s, bw, d_T, nb, bs, n_last, false, d_U, d_pidx, nullptr);
-    if (!rc) rc = mtf_run(s, mw, d_U, nb, d_len);
-    if (!rc) {
-      if (fast) hipLaunchKernelGGL(bwtc_defsum, dim3(nb), dim3(64), 0, s, mw.b, d_steps, step_stride, d_nsteps);
-      else if (getenv("CJS_BWTC_SERIAL_MODEL")) hipLaunchKernelGGL(bwtc_fenwick, dim3(nb), dim3(64), 0, s, mw.b, d_steps, step_stride, d_nsteps);
-      else hipLaunchKernelGGL(bwtc_fenwick_par, dim3(nb), dim3(64), 0, s, mw.b, d_steps, step_stride, d_nsteps, getenv("CJS_BWTC_FORCE_SERIAL") ? atoi(getenv("CJS_BWTC_FORCE_SERIAL")) : 0);
-      if (hipGetLastError() != hipSuccess) rc = CJS_E_HIP;
-      if (!rc && !fast && getenv("CJS_BWTC_CHECK")) {               // debug: the one-symbol-at-a-time kernel must give the same steps
-        uint64_t* d_ref = nullptr; uint32_t* d_nref = nullptr;
-        if (hipMalloc((void**)&d_ref, 8 * (size_t)nb * step_stride) == hipSuccess && hipMalloc((void**)&d_nref, 4 * (size_t)nb) == hipSuccess) {
-          hipLaunchKernelGGL(bwtc_fenwick, dim3(nb), dim3(64), 0, s, mw.b, d_ref, step_stride, d_nref);
-          std::vector<uint32_t> na(nb), nr(nb);
-          (void)hipMemcpyAsync(na.data(), d_nsteps, 4 * (size_t)nb, hipMemcpyDeviceToHost, s);
-          (void)hipMemcpyAsync(nr.data(), d_nref, 4 * (size_t)nb, hipMemcpyDeviceToHost, s);
-          (void)hipStreamSynchronize(s);
-          for (uint32_t k = 0; k < nb; k++) {
-            const uint32_t m = na[k] < nr[k] ? na[k] : nr[k];
-            std::vector<uint64_t> a(m), r(m);
-            if (m) { (void)hipMemcpy(a.data(), d_steps + (size_t)k * step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); (void)hipMemcpy(r.data(), d_ref + (size_t)k * step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); }
-            uint32_t i = 0; while (i < m && a[i] == r[i]) i++;
-            if (i < m || na[k] != nr[k]) {
-              fprintf(stderr, "[cjs bwtc check] block %u: steps %u vs %u, first difference at %u", k, na[k], nr[k], i);
-              for (uint32_t q = i > 2 ? i - 2 : 0; q < i + 3 && q < m; q++) fprintf(stderr, "  [%u] %llx | %llx", q, (unsigned long long)a[q], (unsigned long long)r[q]);
-              fprintf(stderr, "\n");
-              break;
-            }
-          }
-        }
-        if (d_ref) (void)hipFree(d_ref);
-        if (d_nref) (void)hipFree(d_nref);
+    // ---- plan: contiguous block ranges per device slot, cut into batches
+    uint32_t nslots = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->n_devices : 0;
+    if (const char* e = getenv("CJS_DEVICES")) nslots = (uint32_t)atoi(e);
+    if (nslots < 1) nslots = 1;
+    if (nslots > 64) nslots = 64;
+    if (nslots > nb) nslots = nb;
+    static const uint32_t first_batch = getenv("CJS_BWTC_FIRST_BATCH") ? (uint32_t)atoi(getenv("CJS_BWTC_FIRST_BATCH")) : BWTC_FIRST_BATCH;
+    const uint32_t share = (nb + nslots - 1) / nslots;
+    J.live.assign(nslots, 0); J.next_seq.assign(nslots, 0);
+    for (uint32_t sl = 0; sl < nslots; sl++) {
+      uint32_t k = std::min<uint32_t>(sl * share, nb);
+      const uint32_t end = std::min<uint32_t>(k + share, nb);
+      int seq = 0;
+      while (k < end) {
+        uint32_t c = std::min<uint32_t>(end - k, BWTC_MAX_BATCH);
+        if (sl == 0 && seq == 0 && first_batch && end - k > 2 * first_batch) c = first_batch;      // the coder starts on this one
+        J.batches.emplace_back();
+        BwtcBatch& B = J.batches.back();
+        B.slot = (int)sl; B.device = nslots == 1 ? dev0 : (int)(sl % (uint32_t)ndev); B.seq = seq++; B.first = k; B.count = c;
+        k += c;
       }
     }
-    std::vector<uint32_t> h_pidx(nb), h_asz(nb), h_nsteps(nb);
-    std::vector<uint8_t> h_alist((size_t)nb * 256);
-    if (!rc && hipMemcpyAsync(h_pidx.data(), d_pidx, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && hipMemcpyAsync(h_asz.data(), mw.b.asz, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && hipMemcpyAsync(h_nsteps.data(), d_nsteps, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && hipMemcpyAsync(h_alist.data(), mw.b.alist, (size_t)nb * 256, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
-    const double ms_gpu = since(T0);
-    const auto T1 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (auto& B : J.batches) workers.emplace_back(bwtc_batch_worker, &J, &B);
     // reciprocals floor(2^64 / tot) + 1 for every total a step can carry (17 bits); tot < 2 keeps the division
     static std::vector<uint64_t> rcp;
     static std::once_flag rcp_once;
     std::call_once(rcp_once, [] { rcp.assign(1u << 17, 0ull); for (uint32_t t = 2; t < (1u << 17); t++) rcp[t] = (uint64_t)(((unsigned __int128)1 << 64) / t) + 1; });
-    // the steps of block k+1 travel (pinned buffer, copy stream) while block k goes through the coder
+    // the steps of block k+1 travel (pinned buffer, copy stream of its batch) while block k goes through the coder
+    const size_t step_stride = 2 * MtfWork::a_stride_for(bs);
     uint64_t* h_buf[2] = {nullptr, nullptr};
-    hipStream_t cs = nullptr; hipEvent_t cev[2] = {nullptr, nullptr};
-    if (!rc && (hipHostMalloc((void**)&h_buf[0], 8 * step_stride) != hipSuccess || hipHostMalloc((void**)&h_buf[1], 8 * step_stride) != hipSuccess ||
-                hipStreamCreate(&cs) != hipSuccess || hipEventCreateWithFlags(&cev[0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&cev[1], hipEventDisableTiming) != hipSuccess)) rc = CJS_E_HIP;
-    auto fetch = [&](uint32_t k) {
-      if (h_nsteps[k] && hipMemcpyAsync(h_buf[k & 1], d_steps + (size_t)k * step_stride, 8 * (size_t)h_nsteps[k], hipMemcpyDeviceToHost, cs) != hipSuccess) return (int)CJS_E_HIP;
-      return hipEventRecord(cev[k & 1], cs) == hipSuccess ? 0 : (int)CJS_E_HIP;
+    if (hipHostMalloc((void**)&h_buf[0], 8 * step_stride, hipHostMallocPortable) != hipSuccess || hipHostMalloc((void**)&h_buf[1], 8 * step_stride, hipHostMallocPortable) != hipSuccess) rc = CJS_E_HIP;
+    size_t bi_of_next = 0;                                           // batch that holds the next block to fetch
+    hipEvent_t pending[2] = {nullptr, nullptr}; int pending_dev[2] = {0, 0};
+    auto wait_batch = [&](size_t bi) -> int {                        // blocks until the batch's GPU work is done
+      const auto Tw = std::chrono::steady_clock::now();
+      std::unique_lock<std::mutex> lk(J.mu);
+      J.cv.wait(lk, [&] { return J.batches[bi].done; });
+      ms_stall += since(Tw);
+      return J.batches[bi].rc;
     };
-    if (!rc && nb) rc = fetch(0);
+    auto fetch = [&](uint32_t k) -> int {
+      while (J.batches[bi_of_next].first + J.batches[bi_of_next].count <= k) bi_of_next++;
+      BwtcBatch& B = J.batches[bi_of_next];
+      CJS_TRY(wait_batch(bi_of_next));
+      const uint32_t r = k - B.first;
+      if (hipSetDevice(B.device) != hipSuccess) return (int)CJS_E_HIP;
+      if (B.nsteps[r] && hipMemcpyAsync(h_buf[k & 1], B.d_steps + (size_t)r * B.step_stride, 8 * (size_t)B.nsteps[r], hipMemcpyDeviceToHost, B.cs) != hipSuccess) return (int)CJS_E_HIP;
+      if (hipEventRecord(B.cev[k & 1], B.cs) != hipSuccess) return (int)CJS_E_HIP;
+      pending[k & 1] = B.cev[k & 1]; pending_dev[k & 1] = B.device;
+      return 0;
+    };
+    auto retire = [&](size_t bi) {                                   // the coder is through with the batch: give its memory back
+      BwtcBatch& B = J.batches[bi];
+      B.release();
+      std::lock_guard<std::mutex> lk(J.mu);
+      J.live[B.slot]--;
+      J.cv.notify_all();
+    };
+    if (!rc) rc = fetch(0);
+    ms_first = since(T0);
+    size_t bi_cur = 0;
     for (uint32_t k = 0; k < nb && !rc; k++) {
+      while (J.batches[bi_cur].first + J.batches[bi_cur].count <= k) { retire(bi_cur); bi_cur++; }
+      const BwtcBatch& B = J.batches[bi_cur];
+      const uint32_t r = k - B.first;
       if (k + 1 < nb) rc = fetch(k + 1);
       if (rc) break;
-      coder.reserve(3 * (size_t)h_nsteps[k] + coder.help + 4096);      // everything this block can emit
-      const uint32_t length = lens[k];
+      const auto Tc = std::chrono::steady_clock::now();
+      coder.reserve(3 * (size_t)B.nsteps[r] + coder.help + 4096);     // everything this block can emit
+      const uint32_t length = k + 1 == nb ? J.n_last : bs;
       if (length == bs) coder.freq(1, 0, 3);                         // "full size block" :1734
       else { coder.freq(1, 1, 3); logdist(coder, (int)bs, length); } // "short block" :1737-1738
-      logdist(coder, (int)bs, h_pidx[k]);                            // :1742
+      logdist(coder, (int)bs, B.pidx[r]);                            // :1742
       uint16_t tree[512]; memset(tree, 0, sizeof tree);              // use-tree :1744-1765
-      for (uint32_t i = 0; i < h_asz[k]; i++) tree[256 + h_alist[(size_t)k * 256 + i]] = 1;
+      for (uint32_t i = 0; i < B.asz[r]; i++) tree[256 + B.alist[(size_t)r * 256 + i]] = 1;
       for (int i = 255; i > 0; i--) tree[i] = (uint16_t)(tree[2 * i] + tree[2 * i + 1]);
       tree[0] = 1;
       for (int i = 1; i < 512; i++) {
@@ -544,24 +664,34 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
         if (i >= 256) coder.shift(1, tree[i] ? 1 : 0, 1);
         else coder.freq(1, tree[i] == 0 ? 0u : tree[i] == full ? 2u : 1u, 3);
       }
-      if (hipEventSynchronize(cev[k & 1]) != hipSuccess) { rc = CJS_E_HIP; break; }
+      if (hipSetDevice(pending_dev[k & 1]) != hipSuccess || hipEventSynchronize(pending[k & 1]) != hipSuccess) { rc = CJS_E_HIP; break; }
       const uint64_t* h_steps = h_buf[k & 1];
       const uint64_t* rc_tab = rcp.data();
-      for (uint32_t i = 0; i < h_nsteps[k]; i++) {                    // the serial tail
+      const uint32_t ns = B.nsteps[r];
+      for (uint32_t i = 0; i < ns; i++) {                             // the serial tail
         const uint64_t st = h_steps[i];
         const uint32_t sy = (uint32_t)(st & 0xFFFF), lt = (uint32_t)((st >> 16) & 0xFFFF), tot = (uint32_t)((st >> 32) & 0x1FFFF);
         if (st & STEP_SHIFT_FLAG) coder.shift(sy, lt, (int)tot);
         else if (tot >= 2) coder.freq_rcp(sy, lt, tot, rc_tab);
         else coder.freq(sy, lt, tot);
       }
+      ms_coder += since(Tc);
     }
-    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwtc] workspace + H2D + BWT + MTF + model %.1f ms, range coder over the step lists (host, serial) %.1f ms\n", ms_gpu, since(T1));
-    if (cs) (void)hipStreamSynchronize(cs);
-    for (int q = 0; q < 2; q++) { if (cev[q]) (void)hipEventDestroy(cev[q]); if (h_buf[q]) (void)hipHostFree(h_buf[q]); }
-    if (cs) (void)hipStreamDestroy(cs);
-    if (s) (void)hipStreamDestroy(s);
-    if (bw.h_counters) (void)hipHostFree(bw.h_counters);
-    arena.destroy();
+    if (rc) { std::lock_guard<std::mutex> lk(J.mu); J.abort = true; J.cv.notify_all(); }
+    for (auto& t : workers) t.join();
+    double ms_gpu_max = 0;
+    for (auto& B : J.batches) { if (!rc && B.rc) rc = B.rc; ms_gpu_max = std::max(ms_gpu_max, B.ms); B.release(); }
+    (void)hipSetDevice(dev0);
+    for (int q = 0; q < 2; q++) if (h_buf[q]) (void)hipHostFree(h_buf[q]);
+    if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwtc] %zu batch(es) on %u slot(s): first step list after %.1f ms, longest batch (workspace + H2D + BWT + MTF + model) %.1f ms, "
+                                             "range coder over the step lists (host, serial) %.1f ms, coder waited for the GPU %.1f ms, total %.1f ms\n",
+                                     J.batches.size(), (unsigned)J.live.size(), ms_first, ms_gpu_max, ms_coder, ms_stall, since(T0));
+    cjs_stats* st = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->stats : nullptr;
+    if (st && !rc) {                                                 // BWTC meaning of the fields: see include/cjs_hip.h
+      memset(st, 0, sizeof *st);
+      st->ms_total = since(T0); st->ms_bwt = ms_gpu_max; st->ms_pack = ms_coder; st->ms_rle1 = ms_stall; st->ms_mtf = ms_first;
+      st->blocks = nb; st->bytes_in = n;
+    }
   }
   if (rc) return rc;
   coder.reserve(coder.help + 64);
@@ -571,7 +701,9 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
   if (!host) return CJS_E_OUT_OF_MEMORY;
   memcpy(host, o.data(), o.size());
   *out = host; *out_n = o.size();
+  if (opts && opts->struct_size >= sizeof(cjs_opts) && opts->stats) opts->stats->bytes_out = o.size();
   return 0;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 
 

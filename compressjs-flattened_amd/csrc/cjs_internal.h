@@ -85,6 +85,7 @@ struct BwtWork {
   uint32_t* counters = nullptr;  // 16: [0] survivors [1] groups [8] tile ticket [9] look-back error
   uint32_t* ghist = nullptr;     // [8][256] digit histograms + [8][256] their exclusive scans (onesweep passes)
   uint32_t* h_counters = nullptr;  // pinned host mirror
+  void release_host() { if (h_counters) (void)hipHostFree(h_counters); h_counters = nullptr; }
   uint32_t hist_tiles = 0, bintot_segs = 0;   // capacity of hist (tiles) and bintot (segments)
   bool no_large_groups = false;    // per bwt_run: no unresolved group exceeds the tile sorter's limit any more
   // segmented sorts round every block up to whole tiles: room for one extra tile per 64 Ki elements

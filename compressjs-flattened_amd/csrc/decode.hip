@@ -41,7 +41,7 @@ namespace cjs {
 constexpr uint64_t MAGIC_BLOCK = 0x314159265359ull, MAGIC_END = 0x177245385090ull;
 constexpr int SPL = 128;                  // one splitter every SPL slots of the LF vector
 
-struct Cand { uint64_t bit; uint32_t kind; uint32_t pad; };      // kind 0 = block, 1 = end of stream
+struct Cand { uint64_t bit; uint32_t kind; uint32_t pad; };      // kind 0 = block, 1 = end of stream; pad = row of the block candidate in the decode buffer (set by the host)
 struct BlockOut {
   uint64_t end_bit;       // first bit after the block's EOB code
   uint32_t count;         // decoded BWT bytes (dbufCount)
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
   const int lane = lane_id();
   BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
   if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
-  uint8_t* tt = tt_all + (size_t)c * dbuf_size;
+  uint8_t* tt = tt_all + (size_t)cands[c].pad * dbuf_size;
   BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
   uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0;
   DEC_MARK(0);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(128) void bz_decode_block_pipe(const uint8_t* __res
     if (threadIdx.x == 0) { BlockOut bo; bo.end_bit = cands[c].bit + 48; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0; outs[c] = bo; }
     return;
   }
-  uint8_t* tt = tt_all + (size_t)c * dbuf_size;
+  uint8_t* tt = tt_all + (size_t)cands[c].pad * dbuf_size;
   uint32_t group_count = 0, n_sel = 0;
   uint64_t pos = 0;
   if (wv == 0) {
@@ -1033,7 +1033,7 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   hipStream_t s = S->s;
   const size_t up_n = (size_t)(S->up_hi - S->up_lo);
   uint8_t* d_raw = nullptr; Cand* d_cand = nullptr; uint32_t* d_count = nullptr;
-  const uint32_t cand_cap = (uint32_t)((S->hi - S->lo) / 64 + 1024);
+  uint32_t cand_cap = (uint32_t)((S->hi - S->lo) / 64 + 1024);      // grown to the exact count if a file of tiny streams has more
   int rc = S->take((void**)&d_raw, up_n + 256 + 16);
   if (!rc) rc = S->take((void**)&d_cand, sizeof(Cand) * cand_cap);
   if (!rc) rc = S->take((void**)&d_count, 64);
@@ -1045,17 +1045,27 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (S->hi > S->lo) hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((S->hi - S->lo + 255) / 256)), dim3(256), 0, s, S->d_in, S->lo, S->hi, S->up_hi, d_cand, cand_cap, d_count);
   uint32_t ncand = 0;
   if (hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
-  if (ncand > cand_cap) { S->rc = CJS_E_DATA_ERROR; return; }
+  if (ncand > cand_cap) {                                             // more magics than planned for (many tiny member streams): scan again with room for all
+    S->drop(d_cand);
+    cand_cap = ncand;
+    if ((rc = S->take((void**)&d_cand, sizeof(Cand) * cand_cap)) != 0) { S->rc = rc; return; }
+    if (hipMemsetAsync(d_count, 0, 64, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+    hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((S->hi - S->lo + 255) / 256)), dim3(256), 0, s, S->d_in, S->lo, S->hi, S->up_hi, d_cand, cand_cap, d_count);
+    if (hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+    if (ncand > cand_cap) { S->rc = CJS_E_HIP; return; }
+  }
   S->cands.resize(ncand);
   if (ncand && hipMemcpy(S->cands.data(), d_cand, sizeof(Cand) * ncand, hipMemcpyDeviceToHost) != hipSuccess) { S->rc = CJS_E_HIP; return; }
   std::sort(S->cands.begin(), S->cands.end(), [](const Cand& a, const Cand& b) { return a.bit < b.bit; });
+  uint32_t nrows = 0;                                              // only block candidates get a row of the decode buffer
+  for (auto& c : S->cands) c.pad = c.kind == 0 ? nrows++ : 0u;
   if (ncand && hipMemcpy(d_cand, S->cands.data(), sizeof(Cand) * ncand, hipMemcpyHostToDevice) != hipSuccess) { S->rc = CJS_E_HIP; return; }
   S->bos.resize(ncand);
   if (!ncand) { S->ms_a = ms_since(T0); return; }
   uint32_t* d_hist = nullptr; BlockOut* d_bo = nullptr;
   static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
   static const bool v2 = getenv("CJS_DECODE_V2") != nullptr;      // the one-wave cooperative loop
-  rc = S->take((void**)&S->d_tt, (size_t)ncand * J->tt_stride);
+  rc = S->take((void**)&S->d_tt, (size_t)(nrows ? nrows : 1) * J->tt_stride);
   if (!rc && (v1 || v2)) rc = S->take((void**)&d_hist, (size_t)ncand * 256 * 4);
   if (!rc) rc = S->take((void**)&d_bo, sizeof(BlockOut) * ncand);
   if (rc) { S->rc = rc; return; }
@@ -1088,8 +1098,9 @@ struct IbScratch {
 
 // batches of the share's chain blocks: [b0, b1) with <= DEC_BATCH_ELEMS elements and <= DEC_BATCH_BLOCKS blocks
 size_t dec_next_batch(const DecJob* J, size_t b0, size_t c1) {
+  static const uint64_t max_el = getenv("CJS_DEC_BATCH_ELEMS") ? strtoull(getenv("CJS_DEC_BATCH_ELEMS"), nullptr, 10) : DEC_BATCH_ELEMS;   // (tests shrink it)
   uint64_t el = 0; size_t b = b0;
-  while (b < c1 && b - b0 < DEC_BATCH_BLOCKS && (b == b0 || el + J->chain[b].count <= DEC_BATCH_ELEMS)) { el += J->chain[b].count; b++; }
+  while (b < c1 && b - b0 < DEC_BATCH_BLOCKS && (b == b0 || el + J->chain[b].count <= max_el)) { el += J->chain[b].count; b++; }
   return b;
 }
 
@@ -1285,7 +1296,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
     if (bo.err != CJS_E_OBSOLETE_INPUT && bo.orig > dbuf_size) { set_detail("initial position out of bounds"); return CJS_E_DATA_ERROR; }   // :1449-1450
     if (bo.err) return bo.err;
     if (bo.count > dbuf_size) return CJS_E_DATA_ERROR;             // decoded with the largest level's limit: this stream's is lower (:1647,1663)
-    IbBlock ib; ib.cand = clocal[(size_t)ci]; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
+    IbBlock ib; ib.cand = S.cands[clocal[(size_t)ci]].pad; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
     J.chain.push_back(ib); J.chain_bits.push_back(bitpos); chain_share.push_back(cshare[(size_t)ci]);
     return 0;
   };
@@ -1325,9 +1336,21 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
       } else break;
     }
   }
-  if (rc) { release_all(); return rc; }
+  // The reference decodes block after block and checks every block's CRC before it reads on (:1756-1761), so an error met
+  // by the walk (bad stream CRC, damaged later block, broken chain) is reported only if every block in front of it
+  // passes its own CRC check: keep it pending and run the rest of the pipeline, without output, over the chain so far.
+  const int pending_rc = rc;
+  char pending_detail[192];
+  snprintf(pending_detail, sizeof pending_detail, "%s", cjs_last_error_detail());
+  clear_detail();
+  rc = 0;
   const size_t nb = J.chain.size();
-  if (nb == 0) { release_all(); if (out) { *out = (uint8_t*)malloc(1); if (!*out) return CJS_E_OUT_OF_MEMORY; } return 0; }
+  if (nb == 0) {
+    release_all();
+    if (pending_rc) { set_detail("%s", pending_detail); return pending_rc; }
+    if (out) { *out = (uint8_t*)malloc(1); if (!*out) return CJS_E_OUT_OF_MEMORY; }
+    return 0;
+  }
   {  // the chain is increasing in bit position, so every share owns one contiguous run of it
     size_t k = 0;
     for (uint32_t i = 0; i < nsh; i++) { sh[i].c0 = k; while (k < nb && chain_share[k] == i) k++; sh[i].c1 = k; }
@@ -1340,7 +1363,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   J.out_off.assign(nb + 1, 0);
   for (size_t k = 0; k < nb; k++) J.out_off[k + 1] = J.out_off[k] + J.chain[k].out_len;
   const uint64_t total = J.out_off[nb];
-  if (out) { J.host = (uint8_t*)malloc(total ? (size_t)total : 1); if (!J.host) { release_all(); return CJS_E_OUT_OF_MEMORY; } }
+  if (out && !pending_rc) { J.host = (uint8_t*)malloc(total ? (size_t)total : 1); if (!J.host) { release_all(); return CJS_E_OUT_OF_MEMORY; } }
   const auto T2 = std::chrono::steady_clock::now();
   rc = for_each_share(sh, &J, dec_phase_c);
   const double ms_c = ms_since(T2);
@@ -1351,6 +1374,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
                                                sh[i].cands.size(), sh[i].c0, sh[i].c1, sh[i].ms_a, sh[i].ms_b, sh[i].ms_c);
   }
   if (rc) { free(J.host); return rc; }
+  if (pending_rc) { set_detail("%s", pending_detail); return pending_rc; }
   if (tab_n) {
     *tab_n = (long)nb;
     for (size_t k = 0; k < nb && (long)k < tab_cap; k++) { tab_pos[k] = J.chain_bits[k]; tab_size[k] = J.chain[k].out_len; }

@@ -42,6 +42,7 @@ extern "C" int cjs_ctx_create(cjs_ctx** out, int device, size_t max_input, int l
 }
 
 extern "C" int cjs_ctx_create_sharded(cjs_ctx** out, int device, size_t max_input, long max_range_blocks, int level) {
+  CJS_GUARD_BEGIN
   if (!out) return CJS_E_INVALID_ARG;
   *out = nullptr;
   if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;
@@ -82,6 +83,7 @@ extern "C" int cjs_ctx_create_sharded(cjs_ctx** out, int device, size_t max_inpu
   if (rc) { cjs_ctx_destroy(c); return rc; }
   *out = c;
   return 0;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 
 extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
@@ -93,7 +95,7 @@ extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
-  if (c->bwt.h_counters) (void)hipHostFree(c->bwt.h_counters);
+  c->bwt.release_host();
   c->rle.release();
   c->arena.destroy();
   delete c;
@@ -116,9 +118,22 @@ struct HostCache {
 static HostCache g_host_cache[MAX_CACHED_DEVICES];
 
 // Shared body: stage 0..tables for the whole stream, then pack blocks [first, first+count).
+static int compress_core_impl(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, long first, long count, bool framed,
+                              uint8_t* d_out, size_t out_cap, uint64_t* out_bits, uint32_t* block_crcs, long crc_cap,
+                              long* total_blocks, cjs_stats* st);
 static int compress_core(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, long first, long count, bool framed,
                          uint8_t* d_out, size_t out_cap, uint64_t* out_bits, uint32_t* block_crcs, long crc_cap,
                          long* total_blocks, cjs_stats* st) {
+  CJS_GUARD_BEGIN
+  const int rc = compress_core_impl(c, d_in, n, level, first, count, framed, d_out, out_cap, out_bits, block_crcs, crc_cap, total_blocks, st);
+  // an early return may leave the block-CRC kernels of the side stream in flight against a context the caller reuses
+  if (rc && c) { if (c->side) (void)hipStreamSynchronize(c->side); if (c->stream) (void)hipStreamSynchronize(c->stream); }
+  return rc;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
+}
+static int compress_core_impl(cjs_ctx* c, const uint8_t* d_in, size_t n, int level, long first, long count, bool framed,
+                              uint8_t* d_out, size_t out_cap, uint64_t* out_bits, uint32_t* block_crcs, long crc_cap,
+                              long* total_blocks, cjs_stats* st) {
   if (!c || level != c->level) return CJS_E_INVALID_ARG;
   if (n > c->max_input) return CJS_E_INVALID_ARG;
   if (((uintptr_t)d_out & 3) != 0) return CJS_E_INVALID_ARG;
@@ -206,29 +221,40 @@ extern "C" int cjs_bzip2_compress_device_range(cjs_ctx* c, const uint8_t* d_in, 
   return compress_core(c, d_in, n, level, first_block, count, false, d_out, out_cap, out_bits, block_crcs, crc_cap, total_blocks, stats);
 }
 
-// One shard of a multi-GPU job: its own device, context and stream; compresses blocks [first, first+count)
-// of the (replicated) input and brings its bare bit string back to the host.
+// One shard of a multi-GPU job: its own device, context and stream.  A shard is a run of consecutive blocks; because the
+// RLE1 state is fresh at every block start, the input bytes [start(first), start(first + count)) form a
+// stream of their own whose blocks are exactly those blocks, so a shard uploads and processes ONLY its byte range and
+// brings its bare bit string back to the host.
 struct Shard {
   int device = 0, rc = 0;
-  long first = 0, count = 0, total_blocks = 0;
+  long first = 0, count = 0;
+  uint64_t byte_lo = 0, byte_hi = 0;
+  const uint8_t* d_resident = nullptr;   // the range is already in this device's memory (the boundary pass put it there)
   uint64_t bits = 0;
   std::vector<uint8_t> bytes;
-  std::vector<uint32_t> crcs;      // all block crcs of the stream; only [first, first+count) are valid
+  std::vector<uint32_t> crcs;            // CRCs of the shard's blocks
 };
-static void run_shard(Shard* sh, const uint8_t* in, size_t n, int level, long max_range_blocks) {
+static void run_shard(Shard* sh, const uint8_t* in, int level) {
+  if (sh->count == 0) return;
   cjs_ctx* c = nullptr;
   if (hipSetDevice(sh->device) != hipSuccess) { sh->rc = CJS_E_HIP; return; }
-  sh->rc = cjs_ctx_create_sharded(&c, sh->device, n, max_range_blocks, level);
+  const size_t n = (size_t)(sh->byte_hi - sh->byte_lo);
+  sh->rc = cjs_ctx_create(&c, sh->device, n, level);
   if (sh->rc) return;
-  const size_t per = (size_t)max_range_blocks * ((size_t)level * 100000);
+  const size_t per = (size_t)sh->count * ((size_t)level * 100000);
   const size_t out_cap = (per + per / 4 + 65536 + 3) & ~(size_t)3;
   uint8_t *d_in = nullptr, *d_out = nullptr;
-  if (hipMalloc((void**)&d_in, n ? n : 4) != hipSuccess) sh->rc = CJS_E_OUT_OF_MEMORY;
+  if (!sh->d_resident && hipMalloc((void**)&d_in, n ? n : 4) != hipSuccess) sh->rc = CJS_E_OUT_OF_MEMORY;
   if (!sh->rc && hipMalloc((void**)&d_out, out_cap) != hipSuccess) sh->rc = CJS_E_OUT_OF_MEMORY;
-  if (!sh->rc && n && hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) sh->rc = CJS_E_HIP;
-  sh->crcs.assign((size_t)Rle1Work::max_blocks_for(n, c->cap) + 1, 0u);
-  if (!sh->rc) sh->rc = cjs_bzip2_compress_device_range(c, d_in, n, level, sh->first, sh->count, d_out, out_cap, &sh->bits, sh->crcs.data(),
-                                                        (long)sh->crcs.size(), &sh->total_blocks, nullptr);
+  if (!sh->rc && d_in && n && hipMemcpyAsync(d_in, in + sh->byte_lo, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) sh->rc = CJS_E_HIP;
+  static const bool dbg = getenv("CJS_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[cjs] shard on device %d: blocks [%ld, %ld), bytes [%llu, %llu): H2D %zu B%s\n", sh->device, sh->first, sh->first + sh->count,
+                   (unsigned long long)sh->byte_lo, (unsigned long long)sh->byte_hi, sh->d_resident ? (size_t)0 : n, sh->d_resident ? " (resident from the boundary pass)" : "");
+  sh->crcs.assign((size_t)sh->count + 1, 0u);
+  long total = 0;
+  if (!sh->rc) sh->rc = cjs_bzip2_compress_device_range(c, sh->d_resident ? sh->d_resident : d_in, n, level, 0, -1, d_out, out_cap, &sh->bits, sh->crcs.data(),
+                                                        (long)sh->crcs.size(), &total, nullptr);
+  if (!sh->rc && total != sh->count) sh->rc = CJS_E_HIP;          // cannot happen: the range was cut at block starts
   if (!sh->rc) {
     sh->bytes.resize((size_t)((sh->bits + 7) / 8) + 8);
     if (hipMemcpy(sh->bytes.data(), d_out, sh->bytes.size(), hipMemcpyDeviceToHost) != hipSuccess) sh->rc = CJS_E_HIP;
@@ -238,19 +264,33 @@ static void run_shard(Shard* sh, const uint8_t* in, size_t n, int level, long ma
   cjs_ctx_destroy(c);
 }
 
-// Multi-GPU host path: blocks are dealt in contiguous ranges to per-GPU worker threads; the only
+// Multi-GPU host path: ONE boundary pass over the stream (device 0: the input start of every block),
+// then blocks are dealt in contiguous ranges to per-GPU worker threads, each of which gets only its byte range; the only
 // cross-shard data are (bit length, block CRCs).  The host funnel-shifts the bit strings into one stream.
-// max_parallel = shards in flight at a time (0 = all): one per GPU bounds the workspace when the ranges are only there to
+// max_parallel = shards in flight at a time (0 = all): one at a time bounds the workspace when the ranges are only there to
 // cut a very large input into pieces (each piece's workspace is ~70 B per byte of its blocks)
 static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshards, uint8_t** out, size_t* out_n, uint32_t max_parallel = 0) {
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CJS_E_NO_DEVICE;
-  const uint32_t cap = (uint32_t)level * 100000u - 19u;
-  // the exact block count needs the boundary pass; the ranges are planned from its upper bound and trimmed by each shard
-  Shard probe; probe.device = 0; probe.first = 0; probe.count = 0;
-  run_shard(&probe, in, n, level, 1);
-  if (probe.rc) return probe.rc;
-  const long total = probe.total_blocks;
+  int ndev = 0, dev0 = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipGetDevice(&dev0) != hipSuccess) return CJS_E_NO_DEVICE;
+  // ---- boundary pass: block starts of the whole stream
+  std::vector<uint64_t> starts;
+  uint8_t* d_all = nullptr;
+  {
+    cjs_ctx* c = nullptr;
+    CJS_TRY(cjs_ctx_create_sharded(&c, 0, n, 1, level));
+    int rc = 0; uint32_t nbk = 0;
+    if (hipMalloc((void**)&d_all, n ? n : 4) != hipSuccess) rc = CJS_E_OUT_OF_MEMORY;
+    if (!rc && hipMemcpyAsync(d_all, in, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc) rc = rle1_run(c->stream, c->rle, d_all, n, &nbk);
+    std::vector<RleBlock> hb(nbk);
+    if (!rc && nbk && hipMemcpy(hb.data(), c->rle.blocks, sizeof(RleBlock) * nbk, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+    cjs_ctx_destroy(c);
+    if (rc) { if (d_all) (void)hipFree(d_all); (void)hipSetDevice(dev0); return rc; }
+    starts.resize((size_t)nbk + 1);
+    for (uint32_t k = 0; k < nbk; k++) starts[k] = hb[k].s;
+    starts[nbk] = n;
+  }
+  const long total = (long)starts.size() - 1;
   const long share = total ? (total + nshards - 1) / nshards : 0;
   std::vector<Shard> sh(nshards);
   std::vector<std::thread> th;
@@ -258,14 +298,18 @@ static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshar
     sh[i].device = (int)(i % (uint32_t)ndev);
     sh[i].first = std::min<long>((long)i * share, total);
     sh[i].count = std::min<long>(share, total - sh[i].first);
+    sh[i].byte_lo = starts[(size_t)sh[i].first]; sh[i].byte_hi = starts[(size_t)(sh[i].first + sh[i].count)];
+    if (sh[i].device == 0) sh[i].d_resident = d_all + sh[i].byte_lo;
   }
-  (void)cap;
   const uint32_t par = max_parallel ? max_parallel : nshards;
   for (uint32_t i0 = 0; i0 < nshards; i0 += par) {
     th.clear();
-    for (uint32_t i = i0; i < nshards && i < i0 + par; i++) th.emplace_back(run_shard, &sh[i], in, n, level, share > 0 ? share : 1);
+    for (uint32_t i = i0; i < nshards && i < i0 + par; i++) th.emplace_back(run_shard, &sh[i], in, level);
     for (auto& t : th) t.join();
   }
+  (void)hipSetDevice(0);
+  (void)hipFree(d_all);
+  (void)hipSetDevice(dev0);
   uint64_t total_bits = 32 + 80;
   for (auto& x : sh) { if (x.rc) return x.rc; total_bits += x.bits; }
   const size_t len = (size_t)((total_bits + 7) / 8);
@@ -283,7 +327,7 @@ static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshar
       if (s) o[ob + i + 1] |= (uint8_t)(b << (8 - s));
     }
     pos += x.bits;
-    for (long k = x.first; k < x.first + x.count; k++) scrc = ((scrc << 1) | (scrc >> 31)) ^ x.crcs[(size_t)k];
+    for (long k = 0; k < x.count; k++) scrc = ((scrc << 1) | (scrc >> 31)) ^ x.crcs[(size_t)k];
   }
   const uint64_t trailer[2] = {0x177245385090ull, scrc}; const int tb[2] = {48, 32};
   for (int q = 0; q < 2; q++) for (int i = tb[q] - 1; i >= 0; i--, pos++) if ((trailer[q] >> i) & 1) o[pos >> 3] |= (uint8_t)(0x80 >> (pos & 7));
@@ -294,19 +338,22 @@ static int compress_multi(const uint8_t* in, size_t n, int level, uint32_t nshar
 extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_t** out, size_t* out_n, const cjs_opts* opts) {
   if (!out || !out_n) return CJS_E_INVALID_ARG;
   *out = nullptr; *out_n = 0;
+  clear_detail();
   if (level < 1 || level > 9) return CJS_E_BAD_LEVEL;                 // J/Bzip2_joined_.js:2208
+  CJS_GUARD_BEGIN
   CJS_TRY(select_device(opts));
   uint32_t nshards = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->n_devices : 0;
   if (const char* e = getenv("CJS_DEVICES")) nshards = (uint32_t)atoi(e);   // lets JS / Python callers shard without an opts struct
-  if (nshards > 1 && n > 0) return compress_multi(in, n, level, nshards > 64 ? 64 : nshards, out, out_n);
   {
-    // very large inputs: block ranges one after the other per GPU, so that the workspace stays bounded (CJS_CHUNK_BYTES, default 2 GiB)
+    // several GPUs and / or a very large input: contiguous block ranges.  With more ranges than devices (inputs above
+    // CJS_CHUNK_BYTES, default 2 GiB, are cut so that a range's workspace stays bounded) the ranges run in waves of one per device.
     static const size_t chunk = getenv("CJS_CHUNK_BYTES") ? (size_t)strtoull(getenv("CJS_CHUNK_BYTES"), nullptr, 10) : ((size_t)2 << 30);
-    if (chunk && n > chunk) {
-      const size_t pieces = (n + chunk / 2 - 1) / (chunk / 2 ? chunk / 2 : 1);
-      int ndev = 0;
-      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CJS_E_NO_DEVICE;
-      return compress_multi(in, n, level, (uint32_t)(pieces > 4096 ? 4096 : pieces), out, out_n, 1);
+    if (nshards > 64) nshards = 64;
+    const size_t pieces = (chunk && n > chunk) ? (n + chunk / 2 - 1) / (chunk / 2 ? chunk / 2 : 1) : 0;
+    if (n > 0 && (nshards > 1 || pieces > 1)) {
+      const uint32_t par = nshards > 1 ? nshards : 1;
+      const uint32_t ranges = (uint32_t)std::max<size_t>(par, std::min<size_t>(pieces, 4096));
+      return compress_multi(in, n, level, ranges, out, out_n, ranges > par ? par : 0);
     }
   }
   // The workspace (~70 B per input byte), the staging buffers and the streams are kept per device between calls
@@ -355,6 +402,7 @@ extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_
   if (rc) { free(host); return rc; }
   *out = host; *out_n = len;
   return 0;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 
 extern "C" void cjs_trim(void) {
@@ -373,6 +421,7 @@ extern "C" void cjs_trim(void) {
 // ------------------------------------------------------------------ stage-level entry points (tests)
 extern "C" int cjs_stage_mtf(const uint8_t* U, const uint8_t* blocks, size_t n, int block_len, uint16_t* A, uint32_t* npos,
                              uint32_t* freq, uint32_t* alphabet, const cjs_opts* opts) {
+  CJS_GUARD_BEGIN
   (void)blocks;   // the used-symbol set of a block equals that of its BWT (a permutation of it)
   CJS_TRY(select_device(opts));
   if (n == 0) return 0;
@@ -406,10 +455,12 @@ extern "C" int cjs_stage_mtf(const uint8_t* U, const uint8_t* blocks, size_t n, 
   if (s) (void)hipStreamDestroy(s);
   arena.destroy();
   return rc;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
 
 extern "C" int cjs_stage_huff(const uint16_t* A, uint32_t npos, uint32_t alphabet, uint8_t* selectors, uint8_t* lengths,
                               uint32_t* ngroups, const cjs_opts* opts) {
+  CJS_GUARD_BEGIN
   CJS_TRY(select_device(opts));
   if (npos == 0 || alphabet == 0 || alphabet > 256) return CJS_E_INVALID_ARG;
   const uint32_t stride = npos;    // any stride >= npos-1 works for the selector buffers
@@ -439,4 +490,5 @@ extern "C" int cjs_stage_huff(const uint16_t* A, uint32_t npos, uint32_t alphabe
   if (s) (void)hipStreamDestroy(s);
   arena.destroy();
   return rc;
+  CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }

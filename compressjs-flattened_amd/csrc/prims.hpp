@@ -10,7 +10,34 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-// inclusive wave scan (sum)
+// ---- gfx950 DPP building blocks (wave64 = four rows of 16 lanes).  One DPP move feeds a lane the value of another lane
+// of its row without touching LDS (a __shfl is a ds_bpermute: an LDS-pipe round trip per step):
+//   row_shr:n   lane i of a row reads lane i-n of the same row (n = 1, 2, 4, 8 -> Hillis-Steele inside the row)
+//   row_bcast:15 / row_bcast:31   lane 15 of every row -> the whole next row / lane 31 -> rows 2 and 3
+// Lanes whose source is out of the row, or whose row is masked off, receive `idv` (the identity of the operation).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t idv, uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)idv, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// inclusive wave scan of a 32-bit value under an associative op with identity idv: 6 DPP moves
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t idv, Op op) {
+  x = op(x, dpp_move<DPP_ROW_SHR1, 0xF>(idv, x));
+  x = op(x, dpp_move<DPP_ROW_SHR2, 0xF>(idv, x));
+  x = op(x, dpp_move<DPP_ROW_SHR4, 0xF>(idv, x));
+  x = op(x, dpp_move<DPP_ROW_SHR8, 0xF>(idv, x));        // every row now holds its own inclusive scan
+  x = op(x, dpp_move<DPP_ROW_BCAST15, 0xA>(idv, x));     // rows 1, 3 += total of rows 0, 2
+  x = op(x, dpp_move<DPP_ROW_BCAST31, 0xC>(idv, x));     // rows 2, 3 += total of rows 0..1
+  return x;
+}
+struct OpAddU32 { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+struct OpMaxU32 { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
+struct OpMaxI32 { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return (int32_t)a > (int32_t)b ? a : b; } };
+struct OpMinU32 { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a < b ? a : b; } };
+
+// inclusive wave scan (sum).  32-bit integers: DPP; other types: shuffle ladder
 template <typename T>
 __device__ __forceinline__ T wave_incl_sum(T x) {
   const int lane = lane_id();
@@ -21,6 +48,8 @@ __device__ __forceinline__ T wave_incl_sum(T x) {
   }
   return x;
 }
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) { return wave_incl_scan_dpp(x, 0u, OpAddU32()); }
+__device__ __forceinline__ int32_t wave_incl_sum(int32_t x) { return (int32_t)wave_incl_scan_dpp((uint32_t)x, 0u, OpAddU32()); }
 template <typename T>
 __device__ __forceinline__ T wave_incl_max(T x) {
   const int lane = lane_id();
@@ -31,24 +60,32 @@ __device__ __forceinline__ T wave_incl_max(T x) {
   }
   return x;
 }
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) { return wave_incl_scan_dpp(x, 0u, OpMaxU32()); }
+__device__ __forceinline__ int32_t wave_incl_max(int32_t x) { return (int32_t)wave_incl_scan_dpp((uint32_t)x, 0x80000000u, OpMaxI32()); }
+// wave reductions: the last lane of the inclusive scan holds the result (one scalar readlane broadcasts it)
 template <typename T>
 __device__ __forceinline__ T wave_sum(T x) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
   return x;
 }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x, 0u, OpAddU32()), 63); }
+__device__ __forceinline__ int32_t wave_sum(int32_t x) { return __builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)x, 0u, OpAddU32()), 63); }
 template <typename T>
 __device__ __forceinline__ T wave_max(T x) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { T y = __shfl_xor(x, d, 64); x = y > x ? y : x; }
   return x;
 }
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x, 0u, OpMaxU32()), 63); }
+__device__ __forceinline__ int32_t wave_max(int32_t x) { return __builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)x, 0x80000000u, OpMaxI32()), 63); }
 template <typename T>
 __device__ __forceinline__ T wave_min(T x) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { T y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
   return x;
 }
+__device__ __forceinline__ uint32_t wave_min(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x, 0xFFFFFFFFu, OpMinU32()), 63); }
 
 // Workgroup exclusive sum.  smem: at least BLOCK/64 entries of T.  Safe to call repeatedly
 // (trailing barrier protects smem reuse).  Returns the exclusive prefix; total in `total`.

@@ -17,7 +17,8 @@ BWTC.compressFile = function (inStream, outStream, props) {
   if (typeof props === 'number' && props >= 1 && props <= 9) { level = props; }   // J/BWTC_joined_.js:1702-1705
   var input = common.coerceInput(inStream);
   var result;
-  try { result = common.addon().bwtcCompress(input.bytes, level); } catch (e) { rethrow(e); }
+  // a stream input without .size makes the reference write varint(0) as the size field (J/BWTC_joined_.js:529-543, SURVEY W1)
+  try { result = common.addon().bwtcCompress(input.bytes, level, input.hasSize ? 0 : 1 /* CJS_FLAG_SIZE_UNKNOWN */); } catch (e) { rethrow(e); }
   return common.deliver(result, outStream);
 };
 BWTC.decompressFile = function (inStream, outStream) {

@@ -16,7 +16,11 @@ function rethrow(e) {
   if (e && typeof e.cjsCode === 'number') {
     var code = e.cjsCode;
     if (code === -20) { throw new Error('Invalid block size multiplier'); }      // J/Bzip2_joined_.js:2208
-    if (Messages[code]) { var t = new TypeError(Messages[code]); t.errorCode = code; throw t; }   // :1385-1391
+    if (Messages[code]) {                                                       // _throw(status, optDetail) :1385-1391
+      var msg = Messages[code];
+      if (e.cjsDetail) { msg += ': ' + e.cjsDetail; }
+      var t = new TypeError(msg); t.errorCode = code; throw t;
+    }
     var g = new Error(e.message); g.errorCode = code; throw g;
   }
   throw e;

@@ -23,6 +23,7 @@ struct Api {
   int (*bzip2_decompress_block)(const uint8_t*, size_t, uint64_t, uint8_t**, size_t*, const cjs_opts*) = nullptr;
   void (*free_)(void*) = nullptr;
   const char* (*strerror_)(int) = nullptr;
+  const char* (*detail_)(void) = nullptr;
   int (*device_count)(void) = nullptr;
   const char* (*version)(void) = nullptr;
   void (*trim)(void) = nullptr;
@@ -46,7 +47,7 @@ bool load_api() {
   SYM(bzip2_compress, "cjs_bzip2_compress") SYM(bzip2_decompress, "cjs_bzip2_decompress")
   SYM(bwtc_compress, "cjs_bwtc_compress") SYM(bwtc_decompress, "cjs_bwtc_decompress")
   SYM(bzip2_table, "cjs_bzip2_table") SYM(bzip2_decompress_block, "cjs_bzip2_decompress_block")
-  SYM(free_, "cjs_free") SYM(strerror_, "cjs_strerror") SYM(device_count, "cjs_device_count") SYM(version, "cjs_version") SYM(trim, "cjs_trim")
+  SYM(free_, "cjs_free") SYM(strerror_, "cjs_strerror") SYM(detail_, "cjs_last_error_detail") SYM(device_count, "cjs_device_count") SYM(version, "cjs_version") SYM(trim, "cjs_trim")
 #undef SYM
   return true;
 }
@@ -60,6 +61,12 @@ napi_value throw_code(napi_env env, int code) {
   napi_create_error(env, nullptr, msg, &err);
   napi_create_int32(env, code, &num);
   napi_set_named_property(env, err, "cjsCode", num);
+  const char* detail = api.detail_ ? api.detail_() : "";        // the reference's optDetail (J/Bzip2_joined_.js:1385-1391)
+  if (detail && detail[0]) {
+    napi_value d;
+    napi_create_string_utf8(env, detail, NAPI_AUTO_LENGTH, &d);
+    napi_set_named_property(env, err, "cjsDetail", d);
+  }
   napi_throw(env, err);
   return nullptr;
 }
@@ -94,19 +101,23 @@ napi_value wrap_result(napi_env env, uint8_t* data, size_t n) {
 template <int KIND>   // 0 bzip2 compress, 1 bzip2 decompress, 2 bwtc compress, 3 bwtc decompress
 napi_value call_stream(napi_env env, napi_callback_info info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.error.c_str()); return nullptr; }
-  size_t argc = 2; napi_value argv[2];
+  size_t argc = 3; napi_value argv[3];
   napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
   const uint8_t* p = nullptr; size_t n = 0;
   if (argc < 1 || !get_bytes(env, argv[0], &p, &n)) { napi_throw_type_error(env, nullptr, "expected a Uint8Array or Buffer"); return nullptr; }
   int32_t arg = KIND == 1 ? 0 : 9;
   if (argc >= 2) napi_get_value_int32(env, argv[1], &arg);
+  uint32_t flags = 0;                                           // third argument: cjs_opts.flags (bwtcCompress: CJS_FLAG_SIZE_UNKNOWN)
+  if (argc >= 3) napi_get_value_uint32(env, argv[2], &flags);
+  cjs_opts opts; memset(&opts, 0, sizeof opts);
+  opts.struct_size = sizeof opts; opts.device = -1; opts.flags = flags;
   uint8_t* out = nullptr; size_t out_n = 0;
   static const uint8_t dummy = 0;
   if (!p) p = &dummy;
   int rc;
   if (KIND == 0) rc = api.bzip2_compress(p, n, arg, &out, &out_n, nullptr);
   else if (KIND == 1) rc = api.bzip2_decompress(p, n, arg, &out, &out_n, nullptr);
-  else if (KIND == 2) rc = api.bwtc_compress(p, n, arg, &out, &out_n, nullptr);
+  else if (KIND == 2) rc = api.bwtc_compress(p, n, arg, &out, &out_n, flags ? &opts : nullptr);
   else rc = api.bwtc_decompress(p, n, &out, &out_n, nullptr);
   if (rc != 0) return throw_code(env, rc);
   return wrap_result(env, out, out_n);

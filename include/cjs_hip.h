@@ -46,6 +46,9 @@ typedef struct cjs_stats {
   uint64_t bytes_in, bytes_out;
   uint32_t bwt_rounds;
 } cjs_stats;
+/* cjs_bwtc_compress fills the same struct with wall-clock times of its two halves: ms_total = whole call, ms_bwt =
+ * longest GPU batch (workspace + H2D + BWT + MTF + model), ms_mtf = time until the first step list reached the host,
+ * ms_pack = serial range coder over the step lists (host), ms_rle1 = time the coder spent waiting for the GPU. */
 
 typedef struct cjs_opts {
   uint32_t struct_size;   /* sizeof(cjs_opts) */
@@ -75,8 +78,10 @@ int cjs_bwtc_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_
 long cjs_bzip2_table(const uint8_t *in, size_t n, int multistream, uint64_t *bitpos, uint32_t *size, long cap, const cjs_opts *opts);
 int cjs_bzip2_decompress_block(const uint8_t *in, size_t n, uint64_t bitpos, uint8_t **out, size_t *out_n, const cjs_opts *opts);
 void cjs_free(void *p);
-/* cjs_bzip2_compress keeps its per-device workspace between calls; cjs_trim() returns it to the driver
- * (environment CJS_NO_CTX_CACHE=1: never keep it). */
+/* Memory kept between calls (allocating and freeing multi-GB scratch costs more than compressing 100 MB):
+ * cjs_bzip2_compress keeps its per-device workspace (~70 B per input byte of the largest call so far) and staging buffers;
+ * cjs_bzip2_decompress / _table / _decompress_block keep their device scratch buffers (~25 B per output byte) in a
+ * per-device pool.  cjs_trim() returns all of it to the driver; environment CJS_NO_CTX_CACHE=1: never keep anything. */
 void cjs_trim(void);
 const char *cjs_strerror(int code);
 /* Detail text of the most recent FAILED call on the calling thread, "" if it had none: the reference's optDetail

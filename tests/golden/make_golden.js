@@ -4,6 +4,7 @@
  *
  *   node tests/golden/make_golden.js small            -> golden_small.json, kat.json
  *   node tests/golden/make_golden.js big <jobname>    -> golden_big_<jobname>.json
+ *   node tests/golden/make_golden.js api              -> golden_api.json (error texts, size-less stream input, mixed-level multistream)
  *
  * The reference is loaded with vm.runInContext (the joined files define top-level vars and
  * export nothing: J/Bzip2_joined_.js:3-10).  Oracle = reference under Node >= 11 (stable
@@ -236,8 +237,70 @@ function main() {
     if (!job) throw new Error('unknown job; one of ' + Object.keys(jobs).join(' '));
     const rec = runCase(mods, job[0], job[1], job[2], job[3], 0);
     fs.writeFileSync(path.join(HERE, 'golden_big_' + process.argv[3] + '.json'), JSON.stringify({ node: process.version, generator_version: 1, cases: [rec] }, null, 1));
+  } else if (mode === 'api') {
+    // Boundary behaviour of the reference recorded as data: what it throws for damaged .bz2 input (message, errorCode,
+    // error class), what BWTC writes for a stream input without .size (SURVEY W1) and that Bunzip.decode restarts with a
+    // new level inside a multistream file (J/Bzip2_joined_.js:1787-1792).
+    const hex = b => Buffer.from(b).toString('hex');
+    const banana = Buffer.from('banana');
+    const good = Buffer.from(mods.Bzip2.compressFile(banana, null, 9));
+    const damaged = (fn) => { const b = Buffer.from(good); fn(b); return b; };
+    const errInputs = [
+      ['garbage', Buffer.from('hello world, this is not bzip2'), false],
+      ['short', Buffer.from('BZ'), false],
+      ['level_0', damaged(b => { b[3] = 0x30; }), false],
+      ['level_colon', damaged(b => { b[3] = 0x3a; }), false],
+      ['block_magic_damaged', damaged(b => { b[5] ^= 0x01; }), false],
+      ['block_crc_flipped', damaged(b => { b[10] ^= 0x80; }), false],
+      ['stream_crc_flipped', damaged(b => { b[b.length - 2] ^= 0x10; }), false],
+      ['randomised_bit', damaged(b => { b[14] |= 0x80; }), false],
+      ['orig_pointer_huge', damaged(b => { b[14] = 0x7f; b[15] = 0xff; b[16] = 0xff; b[17] |= 0x80; }), false],
+      ['payload_bit_flip', damaged(b => { b[24] ^= 0x04; }), false],
+      ['truncated', good.slice(0, 20), false],
+      ['second_member_bad_magic', Buffer.concat([good, Buffer.from('BZx9garbage')]), true],
+      ['second_member_bad_level', Buffer.concat([good, Buffer.from('BZh0garbage')]), true],
+      ['trailing_garbage_single_stream', Buffer.concat([good, Buffer.from('BZx9garbage')]), false],
+    ];
+    const errors = errInputs.map(([name, input, multi]) => {
+      const rec = { name: name, input_hex: hex(input), multistream: multi };
+      try {
+        const out = mods.Bzip2.decompressFile(new Uint8Array(input), null, multi);
+        rec.ok = true; rec.out_hex = hex(out);
+      } catch (e) { rec.ok = false; rec.error_class = e.constructor.name; rec.message = e.message; rec.errorCode = e.errorCode === undefined ? null : e.errorCode; }
+      return rec;
+    });
+    const levelErr = [0, 10, -1, 5.5].map(lv => {
+      try { mods.Bzip2.compressFile(new Uint8Array(banana), null, lv); return { level: lv, ok: true }; }
+      catch (e) { return { level: lv, ok: false, error_class: e.constructor.name, message: e.message }; }
+    });
+    const asStream = (buf, withSize) => { let pos = 0; const st = { readByte: function () { return pos < buf.length ? buf[pos++] : -1; } }; if (withSize) st.size = buf.length; return st; };
+    const smallText = build({ kind: 'textgen', n: 3000, seed: 5 });
+    const sizeless = [];
+    [['empty', new Uint8Array(0)], ['banana', new Uint8Array(banana)], ['textgen_3000_s5', smallText]].forEach(([name, data]) => {
+      [1, 9].forEach(level => {
+        sizeless.push({ name: name, level: level, input_hex: name === 'textgen_3000_s5' ? null : hex(data),
+                        no_size_hex: hex(mods.BWTC.compressFile(asStream(data, false), null, level)),
+                        with_size_hex: hex(mods.BWTC.compressFile(asStream(data, true), null, level)),
+                        array_hex: hex(mods.BWTC.compressFile(data, null, level)),
+                        bzip2_no_size_hex: hex(mods.Bzip2.compressFile(asStream(data, false), null, level)) });
+      });
+    });
+    const bwtcErrors = [Buffer.from('bwtx\x81\x09', 'binary'), Buffer.from('nope')].map(input => {
+      try { mods.BWTC.decompressFile(new Uint8Array(input)); return { input_hex: hex(input), ok: true }; }
+      catch (e) { return { input_hex: hex(input), ok: false, error_class: e.constructor.name, message: e.message }; }
+    });
+    const A = { kind: 'textgen', n: 150000, seed: 21 }, B = { kind: 'xorshift', n: 40000, seed: 77, mask: 15, add: 97 }, C = { kind: 'repeat', unit_hex: '616263', n: 1000 };
+    const parts = [[A, 1], [B, 9], [C, 4]];
+    const cat = Buffer.concat(parts.map(([r, lv]) => Buffer.from(mods.Bzip2.compressFile(build(r), null, lv))));
+    const multiOut = mods.Bzip2.decompressFile(new Uint8Array(cat), null, true);
+    const singleOut = mods.Bzip2.decompressFile(new Uint8Array(cat), null, false);
+    const mixed = { parts: parts.map(([r, lv]) => ({ recipe: r, level: lv })), stream_len: cat.length, stream_sha256: sha256(cat),
+                    multistream_out_len: multiOut.length, multistream_out_sha256: sha256(multiOut),
+                    single_out_len: singleOut.length, single_out_sha256: sha256(singleOut) };
+    fs.writeFileSync(path.join(HERE, 'golden_api.json'), JSON.stringify({ node: process.version, bzip2_decode_errors: errors, bzip2_level_errors: levelErr,
+      bwtc_stream_input: sizeless, bwtc_decode_errors: bwtcErrors, mixed_level_multistream: mixed }, null, 1));
   } else {
-    console.error('usage: make_golden.js small | big <job>');
+    console.error('usage: make_golden.js small | big <job> | api');
     process.exit(2);
   }
 }

@@ -273,27 +273,167 @@ def test_chunked_large_input_path_is_bit_exact(oracle):
     assert rc == 0 and rc_s == "0" and sha == support.sha256(want)
 
 
-def test_onesweep_variant_is_bit_exact(hip, oracle, monkeypatch):
-    # the opt-in look-back radix passes must give the same stream
-    data = recipes.textgen(2500000, 4)
-    rc, want = oracle.bzip2_compress(data, 9)
+def _run_variant(env, n, seed, level):
+    """HipLib().bzip2_compress in a fresh process under `env` (the toggles are read once per process) -> (rc, sha256)"""
     import subprocess, sys as _sys
     code = ("import sys; sys.path.insert(0, 'tests'); import torch, support, recipes, numpy as np; "
-            "d = recipes.textgen(2500000, 4); rc, out = support.HipLib().bzip2_compress(d, 9); "
-            "print(rc, support.sha256(out))")
-    env = dict(os.environ, CJS_ONESWEEP="1")
-    out = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+            "d = recipes.textgen(%d, %d); rc, out = support.HipLib().bzip2_compress(d, %d); "
+            "print(rc, support.sha256(out))" % (n, seed, level))
+    out = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), cwd=ROOT, timeout=300)
     assert out.returncode == 0, out.stderr[-1500:]
     rc_s, sha = out.stdout.split()
-    assert rc_s == "0" and sha == support.sha256(want)
+    return int(rc_s), sha
+
+
+@pytest.mark.parametrize("env", [{"CJS_R1_PACKED": "0"}, {"CJS_R1_PACKED": "1"}, {"CJS_APPLY_HALVES": "0"}, {"CJS_APPLY_HALVES": "2"},
+                                 {"CJS_TILE_SORT": "radix"}, {"CJS_TILE_SORT": "count"}, {"CJS_NO_TILE_SORT": "1"}, {"CJS_NO_SEGMENTED_SORT": "1"},
+                                 {"CJS_R1_PACKED": "1", "CJS_APPLY_HALVES": "2", "CJS_TILE_SORT": "radix"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
+def test_suffix_sort_variants_are_bit_exact(oracle, env):
+    # every A/B toggle of the suffix sorter (round-1 record format, two-sweep rank scatter, tile sorter flavour, fallbacks)
+    # must give the same stream: 2.5 MB at level 9 (three blocks) and 1.2 MB at level 1 (13 blocks: the two-sweep path needs >= 8)
+    cases = [(2500000, 4, 9), (1200000, 6, 1)]
+    if "CJS_APPLY_HALVES" in env:
+        cases.append((7400000, 8, 9))        # nine level-9 blocks: the two-sweep gather / scatter of rounds >= 2 runs for several rounds
+    for n, seed, level in cases:
+        rc, want = oracle.bzip2_compress(recipes.textgen(n, seed), level)
+        rc_v, sha = _run_variant(env, n, seed, level)
+        assert rc == 0 and rc_v == 0 and sha == support.sha256(want), (env, n, level)
+
+
+def test_bwtc_100m_golden(hip):
+    # BASELINE.json configs[3] at 100 MB: BWTC -9, golden cut by the reference JS
+    case = support.load_golden("golden_big_bwtc_9_100m.json")["cases"][0]
+    data = recipes.build(case["recipe"])
+    rc, out = hip.bwtc_compress(data, 9)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == case["out_len"] and support.sha256(out) == case["out_sha256"]
+
+
+def test_bzip2_100m_compress_golden_then_decompress(hip):
+    # BASELINE.json configs[4] at 100 MB: the reference-identical -9 stream decompressed on the GPU gives the input back
+    case = support.load_golden("golden_big_bzip2_9_100m.json")["cases"][0]
+    data = recipes.build(case["recipe"])
+    rc, comp = hip.bzip2_compress(data, 9)
+    assert rc == 0 and comp.size == case["out_len"] and support.sha256(comp) == case["out_sha256"]
+    rc, back = hip.bzip2_decompress(comp)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert back.size == data.size and support.sha256(back) == case["in_sha256"]
+    rc, tab = hip.bzip2_table(comp)
+    assert rc == 0 and len(tab) == 112 and sum(sz for _, sz in tab) == data.size
+
+
+def test_sharded_decompress_equals_single(hip, oracle, monkeypatch):
+    # CJS_DEVICES=3: three byte-range shares (all on GPU 0 here), each scans / decodes the candidates that start in its
+    # share; chain walk and offsets on the host.  Level 9 (few big blocks per share), level 1 (many) and a mixed multistream.
+    m = support.load_golden("golden_api.json")["mixed_level_multistream"]
+    cases = []
+    for n, seed, level in ((10000000, 1, 9), (4000000, 3, 1)):
+        d = recipes.textgen(n, seed)
+        rc, comp = hip.bzip2_compress(d, level)
+        assert rc == 0
+        cases.append((comp, d, 0))
+    parts = [recipes.build(p["recipe"]) for p in m["parts"]]
+    cat = np.concatenate([hip.bzip2_compress(d, p["level"])[1] for d, p in zip(parts, m["parts"])])
+    cases.append((cat, np.concatenate(parts), 1))
+    for ndev in ("2", "3", "5"):
+        monkeypatch.setenv("CJS_DEVICES", ndev)
+        for comp, want, multi in cases:
+            rc, out = hip.bzip2_decompress(comp, multi)
+            assert rc == 0, (ndev, hip.L.cjs_strerror(rc))
+            assert out.size == want.size and np.array_equal(out, want), ndev
+        # a damaged block in the middle share is reported with the reference's code
+        bad = cases[0][0].copy()
+        bad[bad.size // 2] ^= 0x40
+        assert hip.bzip2_decompress(bad)[0] in (-5, -2)
+        monkeypatch.delenv("CJS_DEVICES")
+
+
+def test_sharded_bwtc_compress_equals_golden(hip, monkeypatch):
+    # CJS_DEVICES=3: three device slots (all GPU 0 here) produce the step lists of their block ranges, the single host coder
+    # consumes them in block order; output == the reference's stream
+    case = support.load_golden("golden_big_bwtc_9_10m.json")["cases"][0]
+    data = recipes.build(case["recipe"])
+    for ndev in ("2", "3"):
+        monkeypatch.setenv("CJS_DEVICES", ndev)
+        rc, out = hip.bwtc_compress(data, 9)
+        monkeypatch.delenv("CJS_DEVICES")
+        assert rc == 0 and out.size == case["out_len"] and support.sha256(out) == case["out_sha256"], ndev
+    # small first batch / single batch give the same stream too
+    for fb in ("0", "1", "3"):
+        import subprocess, sys as _sys
+        code = ("import sys; sys.path.insert(0, 'tests'); import torch, support, recipes; "
+                "d = recipes.textgen(10000000, 1); rc, out = support.HipLib().bwtc_compress(d, 9); print(rc, support.sha256(out))")
+        o = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, CJS_BWTC_FIRST_BATCH=fb), cwd=ROOT, timeout=300)
+        assert o.returncode == 0 and o.stdout.split() == ["0", case["out_sha256"]], (fb, o.stderr[-800:])
+
+
+def test_multistream_with_more_than_65535_blocks(hip, oracle):
+    # many tiny concatenated streams: the per-block kernels run in slabs of 65535 blocks
+    one = oracle.bzip2_compress(b"x", 1)[1]
+    two = oracle.bzip2_compress(b"yz", 1)[1]
+    reps = 35000
+    cat = np.concatenate([np.tile(np.concatenate([one, two]), reps)])
+    rc, out = hip.bzip2_decompress(cat, 1)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == 3 * reps and out.tobytes() == b"xyz" * reps
+    hip.L.cjs_trim()
+
+
+def test_bwtc_decompress_negative_inputs(hip, oracle):
+    # truncated / bit-flipped streams (DefSum model at level 1, Fenwick model at level 9): an error code or different
+    # bytes, never a crash; a stream of thousands of empty blocks decodes to nothing
+    data = recipes.textgen(400000, 13)
+    for level in (1, 9):
+        rc, comp = oracle.bwtc_compress(data, level)
+        assert rc == 0
+        assert np.array_equal(hip.bwtc_decompress(comp)[1], data)
+        for cut in (comp.size - 5, comp.size // 2, 9):
+            rc, out = hip.bwtc_decompress(comp[:cut])
+            assert rc != 0 or not np.array_equal(out, data)
+        rng = np.random.default_rng(level)
+        for _ in range(8):
+            bad = comp.copy()
+            bad[int(rng.integers(8, comp.size - 8))] ^= 1 << int(rng.integers(0, 8))
+            rc, out = hip.bwtc_decompress(bad)
+            assert rc in (0, -5)
+    from test_host_logic import _forged_empty_blocks
+    rc, out = hip.bwtc_decompress(_forged_empty_blocks(60000))
+    assert rc == 0 and out.size == 0
+
+
+@pytest.mark.parametrize("extra", [["--mb", "8"], ["--strong-mb", "20"]], ids=["weak", "strong"])
+def test_bench_two_ranks_hip_path_gloo(extra):
+    # the N>1 path of bench.py with the HIP pipeline on every rank: two processes under torch.distributed.run, gloo for
+    # the barriers, both on GPU 0 (BENCH_FORCE_DEVICE0); every rank's fragment is round-tripped against the stream
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--backend", "gloo", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, BENCH_FORCE_DEVICE0="1"), cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2500:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verify"]["round_trip_all_ranks"] is True and line["value"] > 0
+    assert line["scaling"] == ("strong" if extra[0] == "--strong-mb" else "weak")
 
 
 @pytest.mark.slow
-def test_1gib_bzip2_golden(hip):
-    # BASELINE.json north_star: bit-identical .bz2 on a 1 GiB enwik8-shaped input (golden cut by the reference JS)
+def test_1gib_goldens_compress_and_decompress(hip):
+    # BASELINE.json north_star / configs[3] / configs[4] at full size: bit-identical .bz2 and .bwtc on the 1 GiB
+    # enwik8-shaped input (goldens cut by the reference JS), and the .bz2 decompressed on the GPU gives the input back
     case = support.load_golden("golden_big_bzip2_9_1g.json")["cases"][0]
     data = recipes.build(case["recipe"])
     assert support.sha256(data) == case["in_sha256"]
-    rc, out = hip.bzip2_compress(data, 9)
+    rc, comp = hip.bzip2_compress(data, 9)
     assert rc == 0, hip.L.cjs_strerror(rc)
-    assert out.size == case["out_len"] and support.sha256(out) == case["out_sha256"]
+    assert comp.size == case["out_len"] and support.sha256(comp) == case["out_sha256"]
+    hip.L.cjs_trim()
+    rc, back = hip.bzip2_decompress(comp)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert back.size == data.size and support.sha256(back) == case["in_sha256"]
+    del back, comp
+    hip.L.cjs_trim()
+    wcase = support.load_golden("golden_big_bwtc_9_1g.json")["cases"][0]
+    rc, out = hip.bwtc_compress(data, 9)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == wcase["out_len"] and support.sha256(out) == wcase["out_sha256"]

@@ -5,7 +5,7 @@ ks=$1; shift
 for e in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmcab
-    env $e timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmcab -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > gpurun_out/pmcab.log 2>&1 || { tail -5 gpurun_out/pmcab.log; exit 1; }
+    env $e timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmcab -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-extra > gpurun_out/pmcab.log 2>&1 || { tail -5 gpurun_out/pmcab.log; exit 1; }
     python3 - "$(ls gpurun_out/pmcab/*/*counter_collection.csv)" "$ks" "$e" "$c" <<'PY'
 import csv,sys
 acc={}
