@@ -970,26 +970,30 @@ int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
 }
 template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, int, int);
 
-static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag) {
-  static const bool radix = getenv("CJS_TILE_SORT") != nullptr && !strcmp(getenv("CJS_TILE_SORT"), "radix");
+// Which tile sorter: the LDS radix version costs the same whatever the groups look like (18 ps per suffix), the counting /
+// bitonic version is cheaper once the groups are tiny (round 2 of the bench text, 7.7 suffixes per group: 1.51 vs 1.82 ms;
+// round 3, 3.5 per group: 0.67 vs 0.64 ms; later rounds up to 2x in favour of counting).  CJS_TILE_SORT=radix|count forces one.
+static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag, uint32_t ngroups) {
+  static const int forced = !getenv("CJS_TILE_SORT") ? 0 : !strcmp(getenv("CJS_TILE_SORT"), "radix") ? 1 : 2;
+  const bool radix = forced ? forced == 1 : (ngroups && A / ngroups >= 5);
   if (radix) hipLaunchKernelGGL(bwt_tile_sort_radix, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
   else hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
 }
 // One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.
 // Works in place on (key[c], val[c]); only the whole-array fallback flips c.
-static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt) {
+static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt, uint32_t ngroups) {
   static const bool no_tiles = getenv("CJS_NO_TILE_SORT") != nullptr;
   if (no_tiles || A < 2 * TS_WIN) return radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, lt);
   const uint32_t Tt = (A + TS_NOM - 1) / TS_NOM, Tg = (A + TS_GT - 1) / TS_GT;
   uint8_t* dflag = (uint8_t*)w.gord;                    // gord is dead between bwt_gather_keys and bwt_apply
   uint32_t* tcount = w.tile_cnt;                        // 3*cap/4096 entries >= cap/2048
   if (w.no_large_groups) {                              // groups only ever split: once none exceeds TS_MAXGRP, none will
-    launch_tile_sort(s, Tt, w.key[c], w.val[c], A, nullptr);
+    launch_tile_sort(s, Tt, w.key[c], w.val[c], A, nullptr, ngroups);
     CJS_HIP_TRY(hipGetLastError());
     return 0;
   }
   CJS_HIP_TRY(hipMemsetAsync(dflag, 1, A, s));
-  launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag);
+  launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag, ngroups);
   hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, tcount);
   hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2, w.h_counters + 2);      // the kernel writes the pinned mirror itself
   CJS_HIP_TRY(hipStreamSynchronize(s));
@@ -1034,23 +1038,26 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   int nsym = segmented ? 7 : (64 - blk_bits) / sym_bits;
   if (nsym > 7) nsym = 7;
   // packed round-1 records (5 bytes + position in one u64, no value array): cyclic, segmented sorts only
-  static const bool env_packed = getenv("CJS_R1_PACKED") != nullptr && atoi(getenv("CJS_R1_PACKED")) != 0;
-  static const int env_halves = getenv("CJS_APPLY_HALVES") ? atoi(getenv("CJS_APPLY_HALVES")) : 0;
+  // defaults from same-box kernel-time A/Bs (profiles/r02_*): packed records + two-sweep rank scatter 18.60 -> 18.15 ms per step
+  static const bool env_packed = getenv("CJS_R1_PACKED") == nullptr || atoi(getenv("CJS_R1_PACKED")) != 0;
+  static const int env_halves = getenv("CJS_APPLY_HALVES") ? atoi(getenv("CJS_APPLY_HALVES")) : 2;
   const bool packed = env_packed && segmented && cyclic;
   if (packed) nsym = 5;
   const SegGeom sg{nb, stride, n_last, tps};
   const GenSrc gen{d_T, cyclic ? 1 : 0, nsym, packed ? 1 : 0};
   if (!segmented) hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0]);
-  uint32_t A = M, h = (uint32_t)nsym, rounds = 0;
+  uint32_t A = M, h = (uint32_t)nsym, rounds = 0, ngroups = 0;
   w.no_large_groups = false;
   int bits = nsym * sym_bits + (segmented ? 0 : blk_bits);
-  const bool sweeps = env_halves >= 2 && nb >= 8;      // two-sweep scheduling of the round-1 rank scatter (see HalfMap)
+  // two-sweep scheduling of the round-1 rank scatter (see HalfMap): pays only with the packed records (the second sweep of the
+  // 12-byte key + value form re-reads more than the merged stores save: 2.15 vs 1.64 ms)
+  const bool sweeps = env_halves >= 2 && nb >= 8 && packed;
   for (;;) {
     if (rounds == 0) {
       if (packed) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
       else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
-    } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt));
+    } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
@@ -1072,7 +1079,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt] round %u h=%u A=%u bits=%d -> A'=%u groups=%u\n", rounds, h, A, bits, A2, NG);
     c = 1 - c; pc = 1 - pc;
-    A = A2;
+    A = A2; ngroups = NG;
     if (A == 0) break;
     if (cyclic && h >= max_n) {     // only groups of equal rotations are left
       hipLaunchKernelGGL(bwt_flush_active, dim3((A + 255) / 256), dim3(256), 0, s, A, w.val[c], w.pos[pc], w.SA);

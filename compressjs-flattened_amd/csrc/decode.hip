@@ -135,6 +135,8 @@ struct BitWin {
 
 // Block header, selector list, code lengths (lane 0, serial) and the decode tables (whole wave).  Executed by ONE wave;
 // the results are wave-uniform scalars.  Returns 0 or a CJS_E_* code.
+__device__ uint32_t g_dec_dbg = 0;      // CJS_DEC_DBG_CAND=k: candidate k prints its header fields (debug)
+#define DEC_DBG(...) do { if (g_dec_dbg == blockIdx.x + 1u) printf(__VA_ARGS__); } while (0)
 __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint32_t& crc, uint32_t& orig, uint32_t& sym_total,
                             uint32_t& group_count, uint32_t& n_sel) {
   int err = 0;
@@ -145,7 +147,9 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     if (r.get(1)) err = CJS_E_OBSOLETE_INPUT;
     orig = r.get(24);
     if (!err && orig > dbuf_size) err = CJS_E_DATA_ERROR;
+    DEC_DBG("[dbg] crc %08x orig %u err %d pos %llu nbits %llu wbyte %llu win %016llx\n", crc, orig, err, (unsigned long long)r.pos, (unsigned long long)r.nbits, (unsigned long long)r.wbyte, (unsigned long long)r.win);
     const uint32_t t = r.get(16);
+    DEC_DBG("[dbg] t %04x pos %llu wbyte %llu win %016llx\n", t, (unsigned long long)r.pos, (unsigned long long)r.wbyte, (unsigned long long)r.win);
     for (int i = 0; i < 256; i++) S.sym_to_byte[i] = 0;
     for (int i = 0; i < 16; i++) if (t & (1u << (15 - i))) {
       const uint32_t k = r.get(16);
@@ -155,6 +159,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     if (!err && (group_count < 2 || group_count > 6)) err = CJS_E_DATA_ERROR;
     n_sel = r.get(15);
     if (!err && n_sel == 0) err = CJS_E_DATA_ERROR;
+    DEC_DBG("[dbg] sym_total %u group_count %u n_sel %u err %d pos %llu\n", sym_total, group_count, n_sel, err, (unsigned long long)r.pos);
     if (!err) {
       for (int i = 0; i < 256; i++) S.mtf[i] = 0;
       for (uint32_t i = 0; i < group_count; i++) S.mtf[i] = (uint8_t)i;
@@ -236,7 +241,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   __builtin_amdgcn_wave_barrier();
   crc = __builtin_amdgcn_readfirstlane(crc);
   orig = __builtin_amdgcn_readfirstlane(orig);
-  r.pos = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
+  r.pos = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);   // (the builtin returns int: no sign extension of a low half >= 2^31)
   return err;
 }
 
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict_
   int err = dec_prologue(S, r, dbuf_size, bo.crc, orig, sym_total, group_count, n_sel);
   DEC_MARK(2);
   uint32_t dbuf_count = 0;
-  r.pos = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
+  r.pos = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);   // (the builtin returns int: no sign extension of a low half >= 2^31)
   r.wbyte = ~0ull >> 4;
   orig = __builtin_amdgcn_readfirstlane(orig);
   if (V == 2) {
@@ -1062,6 +1067,7 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (ncand && hipMemcpy(d_cand, S->cands.data(), sizeof(Cand) * ncand, hipMemcpyHostToDevice) != hipSuccess) { S->rc = CJS_E_HIP; return; }
   S->bos.resize(ncand);
   if (!ncand) { S->ms_a = ms_since(T0); return; }
+  if (const char* e = getenv("CJS_DEC_DBG_CAND")) { const uint32_t v = (uint32_t)atoi(e) + 1u; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_dbg), &v, 4); }
   uint32_t* d_hist = nullptr; BlockOut* d_bo = nullptr;
   static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
   static const bool v2 = getenv("CJS_DECODE_V2") != nullptr;      // the one-wave cooperative loop
