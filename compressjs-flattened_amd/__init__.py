@@ -8,6 +8,7 @@ There is no CPU fallback: if the library or a GPU is missing every call raises.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -90,15 +91,25 @@ def _coerce_input(data):
     return np.ascontiguousarray(data, dtype=np.uint8)
 
 
-def _stream_call(fn, data, *mid):
+def _adopt(out, n):
+    """the library's malloc'd result as a uint8 ndarray without a copy; cjs_free runs when the array is collected
+    (what the N-API addon does with an external ArrayBuffer and a finalizer)"""
     L = load_library()
+    if not n:
+        L.cjs_free(out)
+        return np.empty(0, np.uint8)
+    addr = ctypes.cast(out, ctypes.c_void_p).value
+    buf = (ctypes.c_uint8 * n).from_address(addr)
+    weakref.finalize(buf, L.cjs_free, ctypes.c_void_p(addr))
+    return np.frombuffer(buf, dtype=np.uint8)
+
+
+def _stream_call(fn, data, *mid):
     data = _coerce_input(data)
     keep = data if data.size else np.zeros(1, dtype=np.uint8)
     out, out_n = u8p(), ctypes.c_size_t(0)
     _check(fn(keep.ctypes.data_as(u8p), data.size, *mid, ctypes.byref(out), ctypes.byref(out_n), None))
-    res = np.ctypeslib.as_array(out, shape=(max(out_n.value, 1),))[: out_n.value].copy() if out_n.value else np.empty(0, np.uint8)
-    L.cjs_free(out)
-    return res
+    return _adopt(out, out_n.value)
 
 
 class Bzip2:
@@ -136,9 +147,7 @@ class BWTC:
         keep = data if data.size else np.zeros(1, dtype=np.uint8)
         out, out_n = u8p(), ctypes.c_size_t(0)
         _check(L.cjs_bwtc_decompress(keep.ctypes.data_as(u8p), data.size, ctypes.byref(out), ctypes.byref(out_n), None))
-        res = np.ctypeslib.as_array(out, shape=(max(out_n.value, 1),))[: out_n.value].copy() if out_n.value else np.empty(0, np.uint8)
-        L.cjs_free(out)
-        return _deliver(res, output)
+        return _deliver(_adopt(out, out_n.value), output)
 
 
 def _deliver(res, output):

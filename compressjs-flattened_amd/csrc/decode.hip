@@ -135,8 +135,6 @@ struct BitWin {
 
 // Block header, selector list, code lengths (lane 0, serial) and the decode tables (whole wave).  Executed by ONE wave;
 // the results are wave-uniform scalars.  Returns 0 or a CJS_E_* code.
-__device__ uint32_t g_dec_dbg = 0;      // CJS_DEC_DBG_CAND=k: candidate k prints its header fields (debug)
-#define DEC_DBG(...) do { if (g_dec_dbg == blockIdx.x + 1u) printf(__VA_ARGS__); } while (0)
 __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint32_t& crc, uint32_t& orig, uint32_t& sym_total,
                             uint32_t& group_count, uint32_t& n_sel) {
   int err = 0;
@@ -147,9 +145,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     if (r.get(1)) err = CJS_E_OBSOLETE_INPUT;
     orig = r.get(24);
     if (!err && orig > dbuf_size) err = CJS_E_DATA_ERROR;
-    DEC_DBG("[dbg] crc %08x orig %u err %d pos %llu nbits %llu wbyte %llu win %016llx\n", crc, orig, err, (unsigned long long)r.pos, (unsigned long long)r.nbits, (unsigned long long)r.wbyte, (unsigned long long)r.win);
     const uint32_t t = r.get(16);
-    DEC_DBG("[dbg] t %04x pos %llu wbyte %llu win %016llx\n", t, (unsigned long long)r.pos, (unsigned long long)r.wbyte, (unsigned long long)r.win);
     for (int i = 0; i < 256; i++) S.sym_to_byte[i] = 0;
     for (int i = 0; i < 16; i++) if (t & (1u << (15 - i))) {
       const uint32_t k = r.get(16);
@@ -159,7 +155,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     if (!err && (group_count < 2 || group_count > 6)) err = CJS_E_DATA_ERROR;
     n_sel = r.get(15);
     if (!err && n_sel == 0) err = CJS_E_DATA_ERROR;
-    DEC_DBG("[dbg] sym_total %u group_count %u n_sel %u err %d pos %llu\n", sym_total, group_count, n_sel, err, (unsigned long long)r.pos);
     if (!err) {
       for (int i = 0; i < 256; i++) S.mtf[i] = 0;
       for (uint32_t i = 0; i < group_count; i++) S.mtf[i] = (uint8_t)i;
@@ -247,202 +242,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
 
 __device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
 #define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
-template <int V>
-__global__ __launch_bounds__(64) void bz_decode_block(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand,
-                                                      uint32_t dbuf_size, uint8_t* __restrict__ tt_all, uint32_t* __restrict__ hist_all,
-                                                      BlockOut* __restrict__ outs) {
-  __shared__ DecShared S;
-  const uint32_t c = blockIdx.x;
-  if (c >= ncand) return;
-  const int lane = lane_id();
-  BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
-  if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
-  uint8_t* tt = tt_all + (size_t)cands[c].pad * dbuf_size;
-  BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
-  uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0;
-  DEC_MARK(0);
-  int err = dec_prologue(S, r, dbuf_size, bo.crc, orig, sym_total, group_count, n_sel);
-  DEC_MARK(2);
-  uint32_t dbuf_count = 0;
-  r.pos = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);   // (the builtin returns int: no sign extension of a low half >= 2^31)
-  r.wbyte = ~0ull >> 4;
-  orig = __builtin_amdgcn_readfirstlane(orig);
-  if (V == 2) {
-    // symbol loop (:1597-1670), wave-cooperative.  All control state is wave-uniform.
-    //  * Huffman: every lane looks up the code that WOULD start at bit pos+lane (bits from a register window, one LDS
-    //    read of the 10-bit table); the real code chain is then followed with readlane hops (length -> next lane),
-    //    so one LDS round trip serves every code inside the next 64 bits;
-    //  * MTF list as bytes in one register per lane (position 4*lane+b): pick by readlane, shift by wave_shr DPP;
-    //  * output bytes collect in a register and leave as 64-byte coalesced stores; runs are filled by all lanes.
-    if (!err) {
-      BitWin bw{in, n, 0, 0, 0};
-      uint64_t pos = r.pos;
-      bw.init(pos, lane);
-      uint32_t L = 0;
-#pragma unroll
-      for (int b = 0; b < 4; b++) L |= (uint32_t)S.sym_to_byte[4 * lane + b] << (8 * b);
-      uint32_t outb = 0, obase = 0;
-      // a RUNA/RUNB run: run_t = sum of (sym+1) << (index in the run).  20 run symbols already give run_t >= 2^20 - 1 >
-      // dbufSize, which the reference rejects when the run ends (:1636) - so the run is cut there with the same error
-      uint32_t run_bit = 0, run_t = 0;
-      uint32_t selector = 0, sym_left = 0; int g = 0;
-      const int lane4m1 = 4 * lane - 1;
-      bool done = false;
-      while (!done && !err) {
-        if (sym_left == 0) {
-          sym_left = 50;
-          if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
-          g = __builtin_amdgcn_readfirstlane((int)S.selectors[selector++]);      // LDS loads count as divergent: say it is uniform
-          if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
-        }
-        bw.ensure(pos, lane);
-        uint32_t e;
-        {
-          const uint32_t d = (uint32_t)((pos >> 5) - bw.base);
-          const uint32_t w0 = bw.word(d), w1 = bw.word(d + 1), w2 = bw.word(d + 2), w3 = bw.word(d + 3);
-          const uint32_t o = (uint32_t)(pos & 31) + (uint32_t)lane, wi = o >> 5;
-          const uint32_t hi = wi == 0 ? w0 : wi == 1 ? w1 : w2, lo = wi == 0 ? w1 : wi == 1 ? w2 : w3;
-          const uint32_t x = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31)) >> 54);
-          e = S.fast[g][x];
-        }
-        uint32_t idx = 0;
-        do {
-          uint32_t ee = __builtin_amdgcn_readlane(e, idx);
-          if (__builtin_expect(ee == 0u || ee == 0x1Fu, 0)) {
-            if (ee) { err = CJS_E_DATA_ERROR; break; }
-            const uint64_t p0 = pos + idx;                     // long code: the reference's bit-by-bit rule
-            int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);
-            const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
-            long long j = bw.peek(p0, i);
-            for (;; i++) {
-              if (i > mx) { err = CJS_E_DATA_ERROR; break; }
-              if (j <= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
-              j = (j << 1) | bw.peek(p0 + i, 1);
-            }
-            if (err) break;
-            j -= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.base[g][i]);
-            if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
-            ee = (__builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]) << 5) | (uint32_t)i;
-          }
-          const uint32_t next_sym = ee >> 5;
-          idx += ee & 31u; sym_left--;
-          if (next_sym <= 1) {                                 // RUNA / RUNB
-            run_t += (next_sym + 1u) << run_bit;
-            if (++run_bit >= 20) { err = CJS_E_DATA_ERROR; break; }
-            continue;
-          }
-          if (run_bit) {
-            run_bit = 0;
-            if (dbuf_count + run_t > dbuf_size) { err = CJS_E_DATA_ERROR; break; }
-            const uint8_t uc = (uint8_t)(__builtin_amdgcn_readlane(L, 0) & 0xFFu);
-            if ((uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;       // pending singles first
-            for (uint32_t q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
-            dbuf_count += run_t;
-            obase = dbuf_count;
-            run_t = 0;
-          }
-          if (next_sym > sym_total) { done = true; break; }     // EOB
-          if (dbuf_count >= dbuf_size) { err = CJS_E_DATA_ERROR; break; }
-          // move to front: list position 4*lane+b is byte b of L.  (A branch-free variant that also ran this block for
-          // run symbols with k = 0 was slower, 159 vs 130 ms: for a lone wave the vector instructions cost more than the branch.)
-          const uint32_t k = next_sym - 1;
-          const uint32_t v = (__builtin_amdgcn_readlane(L, k >> 2) >> (8u * (k & 3u))) & 0xFFu;
-          const uint32_t vv = v << 24;
-          const uint32_t up = __builtin_amdgcn_update_dpp(vv, L, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 keeps vv
-          const uint32_t shifted = __builtin_amdgcn_alignbit(L, up, 24);                                     // (L << 8) | (up >> 24)
-          int nb = (int)k - lane4m1;                                                                          // bytes of this lane that move
-          nb = nb < 0 ? 0 : nb > 4 ? 4 : nb;
-          const uint32_t m = (uint32_t)((1ull << (8 * nb)) - 1ull);
-          L = (shifted & m) | (L & ~m);
-          const uint32_t slot = dbuf_count - obase;
-          outb = (uint32_t)lane == slot ? v : outb;
-          dbuf_count++;
-          if (slot == 63) { tt[obase + lane] = (uint8_t)outb; obase = dbuf_count; }
-        } while (idx < 64 && sym_left);
-        pos += idx;
-      }
-      if (!err && (uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;
-      if (!err && orig >= dbuf_count) err = CJS_E_DATA_ERROR;    // :1677
-      r.pos = pos > r.nbits ? r.nbits : pos;
-    }
-  } else {
-  // symbol loop (:1597-1670).  Executed by ALL lanes on identical (wave-uniform) state, so the serial Huffman
-  // decode costs the same as on one lane while the move-to-front shift and the run fills use the 64 lanes.
-  if (!err) {
-    int32_t run_pos = 0; long long run_t = 0;
-    uint32_t selector = 0; int sym_left = 0, g = 0;
-    for (;;) {
-      if (!(sym_left--)) {
-        sym_left = 49;
-        if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
-        g = S.selectors[selector++];
-        if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
-      }
-      uint32_t next_sym;
-      const uint32_t x = r.peek(10);
-      const uint16_t e = S.fast[g][x];
-      if (e && e != 0x1F) { next_sym = e >> 5; r.skip(e & 31); }
-      else if (e == 0x1F) { err = CJS_E_DATA_ERROR; break; }
-      else {                                                 // long code: the reference's bit-by-bit rule
-        int i = S.minlen[g];
-        long long j = r.get(i);
-        for (;; i++) {
-          if (i > S.maxlen[g]) { err = CJS_E_DATA_ERROR; break; }
-          if (j <= (long long)S.limit[g][i]) break;
-          j = (j << 1) | r.get(1);
-        }
-        if (err) break;
-        j -= (long long)S.base[g][i];
-        if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
-        next_sym = S.permute[g][j];
-      }
-      if (next_sym <= 1) {                                   // RUNA / RUNB
-        if (!run_pos) { run_pos = 1; run_t = 0; }
-        run_t += next_sym == 0 ? (long long)run_pos : 2 * (long long)run_pos;
-        run_pos = (int32_t)((uint32_t)run_pos << 1);
-        continue;
-      }
-      if (run_pos) {
-        run_pos = 0;
-        if ((long long)dbuf_count + run_t > (long long)dbuf_size) { err = CJS_E_DATA_ERROR; break; }
-        const uint8_t uc = S.sym_to_byte[S.mtf[0]];
-        const uint32_t old = S.byte_count[uc];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) S.byte_count[uc] = old + (uint32_t)run_t;
-        for (long long q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
-        dbuf_count += (uint32_t)run_t;
-      }
-      if (next_sym > sym_total) break;                        // EOB
-      if (dbuf_count >= dbuf_size) { err = CJS_E_DATA_ERROR; break; }
-      const uint32_t k = next_sym - 1;
-      const uint8_t v = S.mtf[k];
-      __builtin_amdgcn_wave_barrier();
-      // move to front: slots 1..k take the value of their left neighbour, highest indices first, 64 per step
-      for (int hi = (int)k; hi >= 1; hi -= 64) {
-        const int idx = hi - lane;
-        uint8_t t8 = 0;
-        if (idx >= 1) t8 = S.mtf[idx - 1];
-        __builtin_amdgcn_wave_barrier();
-        if (idx >= 1) S.mtf[idx] = t8;
-        __builtin_amdgcn_wave_barrier();
-      }
-      const uint8_t uc = S.sym_to_byte[v];
-      const uint32_t oldc = S.byte_count[uc];
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) { S.mtf[0] = v; S.byte_count[uc] = oldc + 1; tt[dbuf_count] = uc; }
-      __builtin_amdgcn_wave_barrier();
-      dbuf_count++;
-    }
-    if (!err && orig >= dbuf_count) err = CJS_E_DATA_ERROR;    // :1677
-  }
-  }
-  DEC_MARK(3);
-  __builtin_amdgcn_wave_barrier();
-  err = __shfl(err, 0, 64);
-  if (V != 2 && !err) for (int i = lane; i < 256; i += 64) hist_all[(size_t)c * 256 + i] = S.byte_count[i];
-  if (lane == 0) { bo.end_bit = r.pos; bo.count = dbuf_count; bo.orig = orig; bo.err = err; outs[c] = bo; }
-}
-
 // ---------------------------------------------------------------- 2b. the same decode as a two-wave pipeline
 // A lone wave issues about one instruction every 8 cycles and a block is one dependent chain of ~650 k symbols, so the
 // chain is cut in two stages that run on different SIMDs of the CU:
@@ -645,6 +444,245 @@ __global__ __launch_bounds__(128) void bz_decode_block_pipe(const uint8_t* __res
     if (!err && P.orig >= P.count) err = CJS_E_DATA_ERROR;      // :1677
     bo.end_bit = P.end_bit; bo.count = P.count; bo.orig = P.orig; bo.crc = P.crc; bo.err = err;
     outs[c] = bo;
+  }
+}
+
+// ---------------------------------------------------------------- 2c. block decode in three stages (default)
+// The Huffman chain of a block is serial (the table changes every 50 symbols, so there is no self-synchronisation to
+// exploit), but nothing BEHIND it has to be:
+//   bz_huff_ops     one wave per candidate follows the code chain (64 table lookups per round + readlane hops) and keeps
+//                   only scalar bookkeeping per symbol: RUNA/RUNB digits fold into the running output offset, every
+//                   rank symbol leaves as (rank, output offset); 64 of them per coalesced store.  No move-to-front, no
+//                   output bytes, no second wave to wait for.
+//   bz_mtf_tiles    the move-to-front of 256 consecutive rank ops of a block, started from the identity list, by one wave
+//                   (list as bytes across the lanes, shift by wave_shr DPP): op j becomes q_j = the slot of the TILE-START
+//                   list it reads, and the tile leaves its permutation P_t.   All tiles of all blocks in parallel.
+//   bz_mtf_compose  one workgroup per block chains the tiles: start list L_(t+1)[p] = L_t[P_t[p]] (an LDS gather per tile).
+//   bz_mtf_emit     one thread per op: byte = L_t[q_j] at its offset, and the zero-rank run behind it (the gap to the next
+//                   op's offset) is filled with the same byte (long runs by the whole wave).
+// Same results as the reference loop (:1597-1670) including its limits (run of >= 20 digits, more bytes than the block size).
+// The per-symbol bookkeeping of up to 64 symbols at once (lane d = d-th symbol in stream order): run digits -> byte counts,
+// running output offset by a wave scan, (rank, offset) of the rank symbols stored densely.  State carried between
+// calls: rank ops so far (j0), bytes so far (off), digits of the zero-rank run that is still open (run_bit).
+__device__ __forceinline__ int huff_flush(uint32_t sd, uint32_t fill, int lane, uint64_t lt, uint32_t dbuf_size, uint8_t* __restrict__ ops,
+                                          uint32_t* __restrict__ opoff, uint32_t& j0, uint32_t& off, uint32_t& run_bit) {
+  if (fill == 0) return 0;
+  const bool val = (uint32_t)lane < fill;
+  const bool isrun = val && sd <= 1u;                          // RUNA / RUNB: bijective base-2 digits of a zero-rank run (:1619-1637)
+  const uint64_t nrm = __ballot(val && !isrun);
+  const uint64_t below = nrm & lt;
+  const uint32_t digit = below ? (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(below)) - 1u : (uint32_t)lane + run_bit;
+  if (__ballot(isrun && digit >= 20u)) return CJS_E_DATA_ERROR;         // 2^20 bytes exceed every block size
+  const uint32_t c = !val ? 0u : isrun ? (sd + 1u) << digit : 1u;     // bytes this symbol emits
+  const uint32_t incl = wave_incl_sum(c);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (off + total > dbuf_size) return CJS_E_DATA_ERROR;                 // (:1647, :1663)
+  if (val && !isrun) {
+    const uint32_t opord = (uint32_t)__popcll(below);
+    ops[j0 + opord] = (uint8_t)(sd - 1u);
+    opoff[j0 + opord] = off + incl - c;
+  }
+  j0 += (uint32_t)__popcll(nrm);
+  off += total;
+  const uint32_t lastd = (uint32_t)__builtin_amdgcn_readlane((int)digit, fill - 1u);
+  run_bit = ((nrm >> (fill - 1u)) & 1ull) ? 0u : lastd + 1u;
+  return 0;
+}
+
+constexpr uint32_t MT_TILE = 256;
+__global__ __launch_bounds__(64) void bz_huff_ops(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
+                                                  uint8_t* __restrict__ ops_all, uint32_t* __restrict__ opoff_all, uint32_t ops_stride,
+                                                  uint8_t* __restrict__ l0_all, uint32_t* __restrict__ nops_all, BlockOut* __restrict__ outs) {
+  __shared__ DecShared S;
+  const uint32_t c = blockIdx.x;
+  if (c >= ncand) return;
+  const int lane = lane_id();
+  BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
+  if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
+  const uint32_t row = cands[c].pad;
+  uint8_t* ops = ops_all + (size_t)row * ops_stride;
+  uint32_t* opoff = opoff_all + (size_t)row * ops_stride;
+  BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
+  uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0, crc = 0;
+  int err = dec_prologue(S, r, dbuf_size, crc, orig, sym_total, group_count, n_sel);
+  uint64_t pos = r.pos;
+  for (int i = lane; i < 256; i += 64) l0_all[(size_t)row * 256 + i] = S.sym_to_byte[i];
+  uint32_t off = 0, j0 = 0;
+  if (!err) {
+    BitWin bw{in, n, 0, 0, 0};
+    bw.init(pos, lane);
+    // Per round (64 bit positions): (1) every lane looks up the code that WOULD start at bit pos + lane; (2) the serial
+    // part is only the walk from code start to code start -- one readlane + add + bit-set per symbol; (3) everything per
+    // symbol (end-of-block test, run digits, output offsets, op compaction) is done across the lanes, for 64 buffered
+    // symbols at a time.  A lone wave issues about one instruction per 8 cycles, so the instruction count of the round is
+    // what is kept small here (a four-window variant with straight-line hops had more of them and was no faster).
+    uint32_t selector = 0, sym_left = 0, run_bit = 0; int g = 0;      // run_bit: digits of the zero-rank run that is still open
+    const uint64_t t_p0 = wall_clock64();
+    const uint64_t lane_bit = 1ull << lane, lt = lane_bit - 1ull;
+    bool done = false, slow = false;
+    uint32_t bufv = 0, fill = 0;
+    while (!done && !err) {
+      if (sym_left == 0) {
+        sym_left = 50;
+        if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
+        g = __builtin_amdgcn_readfirstlane((int)S.selectors[selector++]);
+        if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
+      }
+      bw.ensure(pos, lane);
+      uint64_t mask = 0; uint32_t sym_l, len_l, adv;
+      if (!slow) {
+        const uint32_t d = (uint32_t)((pos >> 5) - bw.base);
+        const uint32_t w0 = bw.word(d), w1 = bw.word(d + 1), w2 = bw.word(d + 2), w3 = bw.word(d + 3);
+        const uint32_t o = (uint32_t)(pos & 31) + (uint32_t)lane, wi = o >> 5;
+        const uint32_t hi = wi == 0 ? w0 : wi == 1 ? w1 : w2, lo = wi == 0 ? w1 : wi == 1 ? w2 : w3;
+        const uint32_t x = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31)) >> 54);
+        const uint32_t e = S.fast[g][x];
+        len_l = e & 31u; sym_l = e >> 5;
+        const uint32_t step = (e == 0u || e == 0x1Fu) ? 64u : len_l;      // a code the 10-bit table cannot decode ends the walk
+        uint32_t idx = 0;
+        do {                                                             // the serial chain: code start -> next code start
+          mask |= 1ull << idx;
+          idx += (uint32_t)__builtin_amdgcn_readlane((int)step, idx);
+        } while (idx < 64u);
+        // the group's table holds for sym_left more symbols only
+        if ((uint32_t)__popcll(mask) > sym_left) mask = __ballot((mask & lane_bit) != 0 && (uint32_t)__popcll(mask & lt) < sym_left);
+        // the round ends behind its last symbol -- unless that one needs the bit-by-bit rule, then in front of it
+        const uint32_t ll = 63u - (uint32_t)__builtin_clzll(mask);
+        const uint32_t stl = (uint32_t)__builtin_amdgcn_readlane((int)step, ll);
+        if (stl == 64u) { mask &= ~(1ull << ll); adv = ll; slow = true; }
+        else adv = ll + stl;
+      } else {
+        int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);            // long code: the reference's bit-by-bit rule (:1605-1616)
+        const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
+        long long j = bw.peek(pos, i);
+        for (;; i++) {
+          if (i > mx) { err = CJS_E_DATA_ERROR; break; }
+          if (j <= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
+          j = (j << 1) | bw.peek(pos + i, 1);
+        }
+        if (err) break;
+        j -= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.base[g][i]);
+        if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
+        sym_l = __builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]);
+        len_l = (uint32_t)i; mask = 1ull; adv = (uint32_t)i; slow = false;
+      }
+      // end of block inside this round?  (:1640)  symbols behind it are not symbols
+      const uint64_t eobm = __ballot((mask & lane_bit) != 0 && sym_l > sym_total);
+      if (eobm) {
+        const uint32_t first = (uint32_t)__builtin_ctzll(eobm);
+        mask &= (1ull << first) - 1ull;
+        adv = first + (uint32_t)__builtin_amdgcn_readlane((int)len_l, first);
+        done = true; slow = false;
+      }
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      if (cnt) {
+        // the round's symbols join a 64-entry buffer (lane = arrival order); the bookkeeping runs when it is full
+        if (fill + cnt > 64u) { err = huff_flush(bufv, fill, lane, lt, dbuf_size, ops, opoff, j0, off, run_bit); fill = 0; if (err) break; }
+        const uint32_t ord = fill + (uint32_t)__popcll(mask & lt);
+        // (lanes that hold no symbol aim at a lane outside [fill, fill + cnt): the one behind it, or lane 0 < fill when it ends at 63)
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(((mask & lane_bit) ? ord : ((fill + cnt) & 63u)) << 2), (int)sym_l);
+        bufv = ((uint32_t)lane >= fill && (uint32_t)lane < fill + cnt) ? got : bufv;
+        fill += cnt;
+        sym_left -= done ? 0u : cnt;
+      }
+      pos += adv;
+    }
+    if (!err) err = huff_flush(bufv, fill, lane, lt, dbuf_size, ops, opoff, j0, off, run_bit);
+    if (lane == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_p0; g_dec_clk[7] = j0; }
+  }
+  err = __builtin_amdgcn_readfirstlane(err);
+  if (err) { j0 = 0; off = 0; }
+  if (!err && orig >= off) err = CJS_E_DATA_ERROR;            // :1677
+  if (lane == 0) {
+    opoff[j0] = off;                                         // the end-of-block pseudo op: where the output ends
+    nops_all[row] = j0;
+    bo.end_bit = pos > n * 8 ? n * 8 : pos; bo.count = err ? 0u : off; bo.orig = orig; bo.crc = crc; bo.err = err;
+    outs[c] = bo;
+  }
+}
+
+// rows are addressed through a 1-D grid (a file of tiny member streams has more rows than grid.y allows)
+__global__ __launch_bounds__(256) void bz_mtf_tiles(uint8_t* __restrict__ ops_all, uint32_t ops_stride, const uint32_t* __restrict__ nops_all,
+                                                    uint8_t* __restrict__ pl_all, uint32_t tiles_per_row, uint32_t tiles_used) {
+  const uint32_t groups = (tiles_used + 3u) >> 2;
+  const uint32_t row = blockIdx.x / groups, t = (blockIdx.x - row * groups) * 4u + (threadIdx.x >> 6);
+  const int lane = lane_id();
+  const uint32_t nops = nops_all[row];
+  if ((size_t)t * MT_TILE >= nops) return;
+  const uint32_t len = nops - t * MT_TILE < MT_TILE ? nops - t * MT_TILE : MT_TILE;
+  uint32_t* opw = reinterpret_cast<uint32_t*>(ops_all + (size_t)row * ops_stride + (size_t)t * MT_TILE);
+  const uint32_t opsreg = opw[lane];
+  uint32_t L = (uint32_t)(4 * lane) * 0x01010101u + 0x03020100u;      // identity list: slot 4*lane+b holds 4*lane+b
+  uint32_t qreg = 0;
+  const int lane4m1 = 4 * lane - 1;
+#pragma unroll 1
+  for (uint32_t j = 0; j < len; j++) {
+    const uint32_t k = ((uint32_t)__builtin_amdgcn_readlane(opsreg, j >> 2) >> (8u * (j & 3u))) & 0xFFu;
+    const uint32_t v = ((uint32_t)__builtin_amdgcn_readlane(L, k >> 2) >> (8u * (k & 3u))) & 0xFFu;
+    const uint32_t up = __builtin_amdgcn_update_dpp(v << 24, L, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const uint32_t shifted = __builtin_amdgcn_alignbit(L, up, 24);
+    int nbm = (int)k - lane4m1;                                          // bytes of this lane that move one slot up
+    nbm = nbm < 0 ? 0 : nbm > 4 ? 4 : nbm;
+    const uint32_t m = (uint32_t)((1ull << (8 * nbm)) - 1ull);
+    L = (shifted & m) | (L & ~m);
+    qreg = (uint32_t)lane == (j >> 2) ? qreg | (v << (8u * (j & 3u))) : qreg;
+  }
+  opw[lane] = qreg;                                                      // (bytes behind len are scratch: the row has room for a whole tile)
+  reinterpret_cast<uint32_t*>(pl_all + ((size_t)row * tiles_per_row + t) * MT_TILE)[lane] = L;
+}
+
+__global__ __launch_bounds__(256) void bz_mtf_compose(const uint32_t* __restrict__ nops_all, const uint8_t* __restrict__ l0_all,
+                                                      uint8_t* __restrict__ pl_all, uint32_t tiles_per_row) {
+  __shared__ uint8_t sl[256];
+  const uint32_t row = blockIdx.x, p = threadIdx.x;
+  const uint32_t nops = nops_all[row];
+  const uint32_t nt = (nops + MT_TILE - 1) / MT_TILE;
+  uint8_t* pl = pl_all + (size_t)row * tiles_per_row * MT_TILE;
+  uint8_t cur = l0_all[(size_t)row * 256 + p];
+  uint8_t idx = nt ? pl[p] : 0;
+  for (uint32_t t = 0; t < nt; t++) {
+    const uint8_t nidx = t + 1 < nt ? pl[(size_t)(t + 1) * MT_TILE + p] : 0;      // the next permutation travels while this one is applied
+    sl[p] = cur;
+    __syncthreads();
+    pl[(size_t)t * MT_TILE + p] = cur;                                            // start list of tile t, in place of its permutation
+    cur = sl[idx];
+    __syncthreads();
+    idx = nidx;
+  }
+}
+
+__global__ __launch_bounds__(256) void bz_mtf_emit(const uint8_t* __restrict__ q_all, const uint32_t* __restrict__ opoff_all, uint32_t ops_stride,
+                                                   const uint32_t* __restrict__ nops_all, const uint8_t* __restrict__ l0_all, const uint8_t* __restrict__ pl_all,
+                                                   uint32_t tiles_per_row, uint32_t tiles_used, uint8_t* __restrict__ tt_all, uint32_t dbuf_size) {
+  const uint32_t row = blockIdx.x / tiles_used, t = blockIdx.x - row * tiles_used;
+  const int lane = lane_id();
+  const uint32_t nops = nops_all[row];
+  if ((size_t)t * MT_TILE >= nops && t) return;
+  const uint8_t* q = q_all + (size_t)row * ops_stride;
+  const uint32_t* opoff = opoff_all + (size_t)row * ops_stride;
+  uint8_t* tt = tt_all + (size_t)row * dbuf_size;
+  const uint32_t j = t * MT_TILE + threadIdx.x;
+  uint32_t o = 0, gap = 0, byte = 0;
+  bool live = j < nops;
+  if (live) {
+    byte = pl_all[((size_t)row * tiles_per_row + t) * MT_TILE + q[j]];
+    o = opoff[j];
+    gap = opoff[j + 1] - o - 1u;                            // the zero-rank run behind this op repeats its byte (the list front)
+    tt[o] = (uint8_t)byte;
+    o++;
+  }
+  if (live && gap <= 16u) { for (uint32_t x = 0; x < gap; x++) tt[o + x] = (uint8_t)byte; live = false; }
+  uint64_t mask = __ballot(live && gap > 16u);
+  while (mask) {                                           // long runs: the whole wave fills
+    const int l = (int)__builtin_ctzll(mask);
+    mask &= mask - 1;
+    const uint32_t jo = (uint32_t)__builtin_amdgcn_readlane((int)o, l), jl = (uint32_t)__builtin_amdgcn_readlane((int)gap, l);
+    const uint32_t jb = (uint32_t)__builtin_amdgcn_readlane((int)byte, l);
+    for (uint32_t x = lane; x < jl; x += 64) tt[jo + x] = (uint8_t)jb;
+  }
+  if (t == 0 && threadIdx.x < 64) {                        // the run in front of the first op repeats the initial list front
+    const uint32_t pre = opoff[0], b0 = l0_all[(size_t)row * 256];
+    for (uint32_t x = lane; x < pre; x += 64) tt[x] = (uint8_t)b0;
   }
 }
 
@@ -1067,31 +1105,54 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (ncand && hipMemcpy(d_cand, S->cands.data(), sizeof(Cand) * ncand, hipMemcpyHostToDevice) != hipSuccess) { S->rc = CJS_E_HIP; return; }
   S->bos.resize(ncand);
   if (!ncand) { S->ms_a = ms_since(T0); return; }
-  if (const char* e = getenv("CJS_DEC_DBG_CAND")) { const uint32_t v = (uint32_t)atoi(e) + 1u; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_dbg), &v, 4); }
-  uint32_t* d_hist = nullptr; BlockOut* d_bo = nullptr;
-  static const bool v1 = getenv("CJS_DECODE_V1") != nullptr;      // the older one-symbol-at-a-time loop, kept for A/B
-  static const bool v2 = getenv("CJS_DECODE_V2") != nullptr;      // the one-wave cooperative loop
+  BlockOut* d_bo = nullptr;
+  static const bool pipe = getenv("CJS_DECODE_PIPE") != nullptr;      // the two-wave pipeline (one workgroup does Huffman + MTF of a block), kept for A/B
   rc = S->take((void**)&S->d_tt, (size_t)(nrows ? nrows : 1) * J->tt_stride);
-  if (!rc && (v1 || v2)) rc = S->take((void**)&d_hist, (size_t)ncand * 256 * 4);
   if (!rc) rc = S->take((void**)&d_bo, sizeof(BlockOut) * ncand);
   if (rc) { S->rc = rc; return; }
   const uint32_t dsz = J->tt_stride;
-  if (v1) hipLaunchKernelGGL(bz_decode_block<1>, dim3(ncand), dim3(64), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_hist, d_bo);
-  else if (v2) hipLaunchKernelGGL(bz_decode_block<2>, dim3(ncand), dim3(64), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_hist, d_bo);
-  else hipLaunchKernelGGL(bz_decode_block_pipe, dim3(ncand), dim3(128), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_bo);
-  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  if (pipe) {
+    hipLaunchKernelGGL(bz_decode_block_pipe, dim3(ncand), dim3(128), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_bo);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+  } else {
+    // three stages: Huffman chain per block -> (rank, offset) ops; move-to-front of all 256-op tiles in parallel; emit
+    const uint32_t ops_stride = (dsz + 256u + 255u) & ~255u, tiles_per_row = ops_stride / MT_TILE, nr = nrows ? nrows : 1;
+    uint8_t *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr;
+    rc = S->take((void**)&d_ops, (size_t)nr * ops_stride);
+    if (!rc) rc = S->take((void**)&d_opoff, 4 * (size_t)nr * ops_stride);
+    if (!rc) rc = S->take((void**)&d_l0, (size_t)nr * 256);
+    if (!rc) rc = S->take((void**)&d_pl, (size_t)nr * ops_stride);
+    if (!rc) rc = S->take((void**)&d_nops, 4 * (size_t)nr);
+    if (rc) { S->rc = rc; return; }
+    if (hipMemsetAsync(d_nops, 0, 4 * (size_t)nr, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+    hipLaunchKernelGGL(bz_huff_ops, dim3(ncand), dim3(64), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, d_ops, d_opoff, ops_stride, d_l0, d_nops, d_bo);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+    uint32_t maxc = 0;
+    for (auto& b : S->bos) if (!b.err && b.count > maxc) maxc = b.count;
+    if (nrows) {
+      const uint32_t tiles_used = std::min<uint32_t>(maxc / MT_TILE + 1u, tiles_per_row);
+      const uint64_t g1 = (uint64_t)nrows * ((tiles_used + 3u) / 4u), g3 = (uint64_t)nrows * tiles_used;
+      if (g3 >= 0x7FFFFFFFull) { S->rc = CJS_E_UNSUPPORTED; return; }
+      hipLaunchKernelGGL(bz_mtf_tiles, dim3((unsigned)g1), dim3(256), 0, s, d_ops, ops_stride, d_nops, d_pl, tiles_per_row, tiles_used);
+      hipLaunchKernelGGL(bz_mtf_compose, dim3(nrows), dim3(256), 0, s, d_nops, d_l0, d_pl, tiles_per_row);
+      hipLaunchKernelGGL(bz_mtf_emit, dim3((unsigned)g3), dim3(256), 0, s, d_ops, d_opoff, ops_stride, d_nops, d_l0, d_pl, tiles_per_row, tiles_used, S->d_tt, dsz);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+    }
+    S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops);
+  }
   if (getenv("CJS_DEBUG")) {
     uint64_t clk[8];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
-      if (v1 || v2) fprintf(stderr, "[cjs dec] candidate 0: header+selectors+lengths %.1f us, tables %.1f us, symbol loop %.1f us\n", (clk[1] - clk[0]) / 100.0, (clk[2] - clk[1]) / 100.0, (clk[3] - clk[2]) / 100.0);
+      if (!pipe) fprintf(stderr, "[cjs dec] candidate 0 (three-stage decode): Huffman chain %.1f us for %llu rank ops\n", clk[6] / 100.0, (unsigned long long)clk[7]);
       else fprintf(stderr, "[cjs dec] candidate 0 (two-wave pipeline): %llu symbols; producer %.1f us, %llu rounds, waited for ring space %llu times; consumer %.1f us, %llu batches, found the ring empty %llu times\n",
                    (unsigned long long)clk[7], clk[6] / 100.0, (unsigned long long)clk[5], (unsigned long long)clk[4], clk[2] / 100.0, (unsigned long long)clk[1], (unsigned long long)clk[0]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
             (unsigned long long)S->hi, (unsigned long long)S->up_lo, (unsigned long long)S->up_hi, up_n, ncand);
   }
-  S->drop(d_cand); S->drop(d_count); S->drop(d_bo); if (d_hist) S->drop(d_hist);
+  S->drop(d_cand); S->drop(d_count); S->drop(d_bo);
   S->ms_a = ms_since(T0);
 }
 

@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
-"""Times Bzip2.decompressFile of the 100 MB level-9 bench stream through the host-buffer C ABI (CJS_DEBUG prints phases)."""
-import importlib, os, sys, time
-import numpy as np
+"""Decompress timing (host-buffer C ABI, wall clock, median of 5 after a warm-up): python tools/dec_time.py <MB> [level]"""
+import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
 import torch  # noqa: F401
-import recipes
-pkg = importlib.import_module("compressjs-flattened_amd")
+import recipes, support
+hip = support.HipLib()
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-lvl = int(sys.argv[2]) if len(sys.argv) > 2 else 9
-data = recipes.textgen(mb * 1000000, 1)
-dbg = os.environ.pop("CJS_DEBUG", None)
-c = pkg.Bzip2.compressFile(data, None, lvl)
-if dbg: os.environ["CJS_DEBUG"] = dbg
-for i in range(3):
-    t0 = time.perf_counter(); back = pkg.Bzip2.decompressFile(c); dt = time.perf_counter() - t0
-    print("decompress %d MB level %d: %.1f ms  %.1f MB/s" % (mb, lvl, dt * 1e3, data.size / dt / 1e6), flush=True)
-assert np.array_equal(back, data)
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+n = (1 << 30) if mb == 1024 else mb * 1000000
+d = recipes.textgen(n, 1)
+rc, comp = hip.bzip2_compress(d, level)
+assert rc == 0
+hip.L.cjs_trim()
+ts = []
+for i in range(6):
+    t0 = time.perf_counter()
+    rc, back = hip.bzip2_decompress(comp)
+    ts.append(time.perf_counter() - t0)
+    assert rc == 0
+ok = bool(np.array_equal(back, d))
+med = float(np.median(ts[1:]))
+print('{"input_bytes": %d, "level": %d, "compressed": %d, "decompress_ms_median": %.2f, "MBps": %.1f, "round_trip": %s, "all_ms": %s}'
+      % (n, level, comp.size, med * 1e3, n / med / 1e6, str(ok).lower(), [round(t * 1e3, 1) for t in ts]))
