@@ -146,6 +146,27 @@ def test_bzip2_decompress_errors_and_multistream(hip, oracle):
     assert hip.bzip2_decompress(both, 1)[1].tobytes() == b"first stream second stream"
 
 
+def test_bzip2_decompress_fuzz_matches_oracle(hip, oracle):
+    # damaged streams: the GPU decoder must come back (no hang, no fault) with the reference's verdict -- same code, and the
+    # same bytes where the damage happens to leave a decodable stream (the oracle is pinned on the reference's error cases)
+    rng = np.random.default_rng(2024)
+    data = np.concatenate([recipes.textgen(250000, 31), np.zeros(3000, np.uint8), rng.integers(0, 256, 20000, dtype=np.uint8)])
+    for level in (1, 9):
+        rc, good = oracle.bzip2_compress(data, level)
+        assert rc == 0
+        for trial in range(60):
+            bad = good.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(0, bad.size))] ^= 1 << int(rng.integers(0, 8))
+            if trial % 10 == 9:
+                bad = bad[: int(rng.integers(8, bad.size))]
+            rc_o, out_o = oracle.bzip2_decompress(bad, trial & 1)
+            rc_h, out_h = hip.bzip2_decompress(bad, trial & 1)
+            assert rc_h == rc_o, (level, trial, rc_h, rc_o)
+            if rc_o == 0:
+                assert np.array_equal(out_h, out_o), (level, trial)
+
+
 def test_bzip2_decompress_10m(hip, oracle):
     data = recipes.textgen(10000000, 1)
     rc, comp = hip.bzip2_compress(data, 9)
