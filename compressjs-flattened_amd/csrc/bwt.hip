@@ -86,7 +86,8 @@ __device__ __forceinline__ uint64_t gen_key(const GenSrc& gs, const SegGeom& sg,
   uint64_t k = 0;
   if (gs.cyclic) {
     k = ((uint64_t)__builtin_bswap32(lo) << 24) | (uint64_t)(__builtin_bswap32(hi) >> 8);     // 7 bytes, first byte on top
-    if (gs.packed) return ((k >> 16) << PK_KEY_LO) | ((uint64_t)(t.seg & 1u) << PK_SHIFT) | (uint64_t)(t.off + loc);
+    if (gs.packed == 1) return ((k >> 16) << PK_KEY_LO) | ((uint64_t)(t.seg & 1u) << PK_SHIFT) | (uint64_t)(t.off + loc);          // bytes 0..4
+    if (gs.packed == 2) return ((k & 0xFFFFFFFFFFull) << PK_KEY_LO) | ((uint64_t)(t.seg & 1u) << PK_SHIFT) | (uint64_t)(t.off + loc);  // bytes 2..6 (two-phase sort)
     k >>= 8 * (7 - gs.nsym);
     k |= (uint64_t)(t.seg & 1u) << (8 * gs.nsym);
   } else {
@@ -804,6 +805,65 @@ __global__ __launch_bounds__(256) void bwt_flush_active(uint32_t A, const uint32
   for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < A; a += (uint64_t)gridDim.x * 256) SA[pos[a]] = val[a];
 }
 
+// Two-phase round 1 (cyclic, packed records): seven bytes of depth at 8 bytes per record.  Phase 1 sorted every block by
+// bytes 2..6; here every sorted slot learns r1 = block-local slot of the head of its (bytes 2..6) class and becomes the
+// phase-2 record  byte0 . byte1 (bits 63..48) | r1 (47..28) | parity (20) | position (19..0); two more stable passes on the
+// top 16 bits then order by (byte0, byte1, class of bytes 2..6), and key >> 20 is the 7-byte group key.
+// Same head bookkeeping as bwt_apply: head masks by ballot, carry of the last head in front of the tile from bwt_scan_tiles.
+__global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __restrict__ key, uint32_t A, Geom g, const uint8_t* __restrict__ T,
+                                                          const uint32_t* __restrict__ tile_cnt, uint32_t Tn, uint64_t* __restrict__ out) {
+  __shared__ uint64_t sk[RS_TILE + 1];
+  __shared__ uint64_t m_nh[64];
+  __shared__ uint32_t wp_head[64];
+  const uint32_t tile = blockIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const uint64_t base = (uint64_t)tile * RS_TILE;
+  const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    sk[e + 1] = e < nvalid ? __builtin_nontemporal_load(key + base + e) : ~0ull;
+  }
+  if (tid == 0) sk[0] = base ? key[base - 1] : ~0ull;
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    const bool nh = e < nvalid && (base + e == 0 || (sk[e] >> PK_SHIFT) != (sk[e + 1] >> PK_SHIFT));
+    const uint64_t mnh = __ballot(nh);
+    if (lane == 0) m_nh[it * 4 + w] = mnh;
+  }
+  __syncthreads();
+  if (w == 0) {
+    const uint64_t mh = m_nh[lane];
+    const uint32_t lastrel = mh ? (uint32_t)lane * 64u + 63u - (uint32_t)__builtin_clzll(mh) + 1u : 0u;
+    const uint32_t im = wave_incl_max(lastrel);
+    uint32_t em = __shfl_up(im, 1, 64);
+    if (lane == 0) em = 0;
+    wp_head[lane] = em;
+  }
+  __syncthreads();
+  const uint32_t carry = tile_cnt[2 * (size_t)Tn + tile];
+  const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    if (e < nvalid) {
+      const int wi = it * 4 + w;
+      const uint64_t hm = m_nh[wi] & le;
+      const uint32_t head_a = hm ? (uint32_t)base + (uint32_t)wi * 64u + 63u - (uint32_t)__builtin_clzll(hm) : wp_head[wi] ? (uint32_t)base + wp_head[wi] - 1u : carry - 1u;
+      const uint32_t a = (uint32_t)base + e;
+      const uint32_t blk = a / g.stride, n = blk_len(g, blk);
+      const uint64_t k = sk[e + 1];
+      const uint32_t p = (uint32_t)k & PK_POS_MASK;
+      const uint8_t* t = T + (size_t)blk * g.stride;
+      const uint32_t b0 = t[p], b1 = t[p + 1 < n ? p + 1 : 0];
+      const uint32_t r1 = head_a - blk * g.stride;
+      __builtin_nontemporal_store(((uint64_t)b0 << 56) | ((uint64_t)b1 << 48) | ((uint64_t)r1 << 28) | (k & ((1ull << (PK_SHIFT + 1)) - 1ull)), out + a);
+    }
+  }
+}
+
 // primary index.  cyclic: last row of the group of rotation 0 (equal rotations are ordered by
 // descending start, J/Bzip2_joined_.js:957-968); sentinel: (row of suffix 0)+1
 __global__ __launch_bounds__(256) void bwt_pidx(Geom g, int cyclic, int leftover, const uint32_t* __restrict__ R, uint32_t* __restrict__ pidx) {
@@ -1041,10 +1101,15 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   // defaults from same-box kernel-time A/Bs (profiles/r02_*): packed records + two-sweep rank scatter 18.60 -> 18.15 ms per step
   static const bool env_packed = getenv("CJS_R1_PACKED") == nullptr || atoi(getenv("CJS_R1_PACKED")) != 0;
   static const int env_halves = getenv("CJS_APPLY_HALVES") ? atoi(getenv("CJS_APPLY_HALVES")) : 2;
+  // two-phase packed sort: bytes 2..6 first, then bytes 0..1 with the class of bytes 2..6 carried as a rank (depth 7)
+  // (same-box A/B: 17.9 -> 17.2 ms per step: the seven passes + the record rebuild cost 4.9 ms instead of 2.8, but 61 M instead of
+  //  83.5 M suffixes stay unresolved behind them and every suffix-round costs ~55 ps)
+  static const bool env_two_phase = getenv("CJS_R1_TWO_PHASE") == nullptr || atoi(getenv("CJS_R1_TWO_PHASE")) != 0;
   const bool packed = env_packed && segmented && cyclic;
-  if (packed) nsym = 5;
+  const bool two_phase = packed && env_two_phase;
+  if (packed) nsym = two_phase ? 7 : 5;
   const SegGeom sg{nb, stride, n_last, tps};
-  const GenSrc gen{d_T, cyclic ? 1 : 0, nsym, packed ? 1 : 0};
+  const GenSrc gen{d_T, cyclic ? 1 : 0, nsym, packed ? (two_phase ? 2 : 1) : 0};
   if (!segmented) hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0]);
   uint32_t A = M, h = (uint32_t)nsym, rounds = 0, ngroups = 0;
   w.no_large_groups = false;
@@ -1055,6 +1120,14 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   for (;;) {
     if (rounds == 0) {
       if (packed) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
+      if (two_phase) {
+        const uint32_t T1 = (A + RS_TILE - 1) / RS_TILE;
+        hipLaunchKernelGGL(bwt_flags, dim3(T1), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T1, PK_SHIFT);
+        hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T1, w.counters, w.h_counters);
+        hipLaunchKernelGGL(bwt_phase2_records, dim3(T1), dim3(256), 0, s, w.key[c], A, g, d_T, w.tile_cnt, T1, w.key[1 - c]);
+        c = 1 - c;
+        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true)));
+      }
       else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
     } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups));

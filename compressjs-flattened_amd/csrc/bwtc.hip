@@ -490,7 +490,7 @@ void bwtc_batch_worker(BwtcJob* J, BwtcBatch* B) {
   MtfWork mw;
   uint8_t *d_T = nullptr, *d_U = nullptr; uint32_t *d_pidx = nullptr, *d_len = nullptr, *d_nsteps = nullptr;
   if (hipSetDevice(B->device) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc) rc = B->arena.init(BwtWork::bytes_needed(elems) + MtfWork::bytes_needed(cnt, bs) + 2 * (elems + 512) + 8 * (size_t)cnt * B->step_stride + 16 * (size_t)cnt + 65536);
+  if (!rc) rc = B->arena.init_pooled(BwtWork::bytes_needed(elems) + MtfWork::bytes_needed(cnt, bs) + 2 * (elems + 512) + 8 * (size_t)cnt * B->step_stride + 16 * (size_t)cnt + 65536);
   if (!rc) rc = B->bw.carve(B->arena, elems);
   if (!rc) rc = mw.carve(B->arena, cnt, bs);
   if (!rc) {

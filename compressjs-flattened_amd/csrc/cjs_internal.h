@@ -30,16 +30,19 @@ void set_detail(const char* fmt, ...);
   } catch (const std::bad_alloc&) { return (oom_value); }              \
   catch (...) { return (other_value); }
 
-// simple device arena: one hipMalloc, bump allocation, 256-byte aligned
+struct DevPool;
+// simple device arena: one hipMalloc (or one buffer of the per-device pool), bump allocation, 256-byte aligned
 struct Arena {
   uint8_t* base = nullptr;
   size_t cap = 0, used = 0;
+  bool pooled = false;
   int init(size_t bytes) {
     CJS_HIP_TRY(hipMalloc((void**)&base, bytes));
-    cap = bytes; used = 0;
+    cap = bytes; used = 0; pooled = false;
     return 0;
   }
-  void destroy() { if (base) (void)hipFree(base); base = nullptr; cap = used = 0; }
+  inline int init_pooled(size_t bytes);      // from DevPool: kept between calls (cjs_trim / CJS_NO_CTX_CACHE give it back)
+  inline void destroy();
   template <typename T> T* take(size_t n) {
     size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
     if (used + bytes > cap) return nullptr;
@@ -67,6 +70,16 @@ struct DevPool {
   static void give(void* p);
   static void trim();
 };
+inline int Arena::init_pooled(size_t bytes) {
+  base = (uint8_t*)DevPool::take(bytes);
+  if (!base) return CJS_E_OUT_OF_MEMORY;
+  cap = bytes; used = 0; pooled = true;
+  return 0;
+}
+inline void Arena::destroy() {
+  if (base) { if (pooled) DevPool::give(base); else (void)hipFree(base); }
+  base = nullptr; cap = used = 0;
+}
 
 constexpr uint32_t RS_TILE = 4096;   // radix-sort tile (256 threads x 16 keys)
 
