@@ -214,9 +214,17 @@ __device__ void fm_serial(uint32_t* leaf, uint32_t* cum, int ns, int e, int symb
   }
 }
 
-__global__ __launch_bounds__(64) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps, int force_serial) {
+// The chunks of a block are a chain only through the model state (leaf counts, steps so far); the 64x64 relation masks of a
+// chunk -- most of its instructions -- depend on nothing but its symbols.  FP_WAVES waves share a block: wave w takes the
+// chunks w, w + FP_WAVES, ...; it builds its masks while the waves in front of it run their state parts, then waits for the
+// baton (an LDS ticket), runs the state part of its chunk on the shared leaf array and passes the baton on.  A lone wave
+// issues about one instruction per 8 cycles, so the block's critical path shrinks to the state parts alone.
+constexpr int FP_WAVES = 8;
+__global__ __launch_bounds__(64 * FP_WAVES) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps, int force_serial) {
   __shared__ uint32_t leaf[328], cum[328];
+  __shared__ uint32_t turn_s, n_s;           // next chunk whose state part may run; coder steps emitted so far
   const uint32_t blk = blockIdx.x;
+  const uint32_t wv = threadIdx.x >> 6;
   const uint32_t asz = mb.asz[blk], nsym = mb.npos[blk] - 1;      // drop bzip2's EOB
   const uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
   uint64_t* out = steps + (size_t)blk * step_stride;
@@ -227,11 +235,13 @@ __global__ __launch_bounds__(64) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __r
   // (symbols >= r0) come first.  All slots below are in that order: slot(s) = (s - r0) mod ns.
   int dpt = 0; while ((2 << dpt) <= 2 * ns - 1) dpt++;                  // depth of the deepest leaf: floor(log2(2ns - 1))
   const int r0 = (1 << dpt) - ns, e = ns - 1 - r0;                      // slot of the escape symbol (symbol ns-1)
-  for (int i = lane; i < 328; i += 64) { leaf[i] = i == e ? (F_INC << 16) : i < ns ? 1u : 0u; cum[i] = 0; }
-  __builtin_amdgcn_wave_barrier();
-  uint32_t n = 0;
+  for (int i = (int)threadIdx.x; i < 328; i += 64 * FP_WAVES) { leaf[i] = i == e ? (F_INC << 16) : i < ns ? 1u : 0u; cum[i] = 0; }
+  if (threadIdx.x == 0) { turn_s = 0; n_s = 0; }
+  __syncthreads();
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;       // lanes < lane
-  for (uint32_t base = 0; base < nsym; base += 64) {
+  const uint32_t nchunks = (nsym + 63u) / 64u;
+  for (uint32_t ch = wv; ch < nchunks; ch += FP_WAVES) {
+    const uint32_t base = ch * 64u;
     const uint32_t cnt = __builtin_amdgcn_readfirstlane(nsym - base < 64 ? nsym - base : 64);
     uint32_t mine = 0xFFFFu;
     if ((uint32_t)lane < cnt) { const int sy = (int)A[base + lane]; mine = (uint32_t)(sy >= r0 ? sy - r0 : sy + ns - r0); }
@@ -243,6 +253,9 @@ __global__ __launch_bounds__(64) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __r
       eqm |= sj == mine ? 1ull << jp : 0ull;
       ltm |= sj < mine ? 1ull << jp : 0ull;
     }
+    // ---- the baton: everything below reads and writes the shared model state
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&turn_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != ch) __builtin_amdgcn_s_sleep(1);
+    uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&n_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     uint32_t start = 0;
     while (start < cnt) {
       fm_build_cum(leaf, cum, ns);
@@ -294,8 +307,14 @@ __global__ __launch_bounds__(64) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __r
         start = c + 1;
       } else start = cnt;
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      __hip_atomic_store(&n_s, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&turn_s, ch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (orders the leaf / n_s stores in front of it)
+    }
   }
-  if (lane == 0) nsteps[blk] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) nsteps[blk] = n_s;
 }
 
 // ---------------------------------------------------------------- DefSumModel (levels 1-5), one lane per block
@@ -514,7 +533,7 @@ void bwtc_batch_worker(BwtcJob* J, BwtcBatch* B) {
   if (!rc) {
     if (J->fast) hipLaunchKernelGGL(bwtc_defsum, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps);
     else if (getenv("CJS_BWTC_SERIAL_MODEL")) hipLaunchKernelGGL(bwtc_fenwick, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps);
-    else hipLaunchKernelGGL(bwtc_fenwick_par, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps, getenv("CJS_BWTC_FORCE_SERIAL") ? atoi(getenv("CJS_BWTC_FORCE_SERIAL")) : 0);
+    else hipLaunchKernelGGL(bwtc_fenwick_par, dim3(cnt), dim3(64 * FP_WAVES), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps, getenv("CJS_BWTC_FORCE_SERIAL") ? atoi(getenv("CJS_BWTC_FORCE_SERIAL")) : 0);
     if (hipGetLastError() != hipSuccess) rc = CJS_E_HIP;
     if (!rc && !J->fast && getenv("CJS_BWTC_CHECK")) {               // debug: the one-symbol-at-a-time kernel must give the same steps
       uint64_t* d_ref = nullptr; uint32_t* d_nref = nullptr;
