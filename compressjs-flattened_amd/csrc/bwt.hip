@@ -1119,16 +1119,17 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   const bool sweeps = env_halves >= 2 && nb >= 8 && packed;
   for (;;) {
     if (rounds == 0) {
-      if (packed) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
-      if (two_phase) {
+      if (packed) {
+        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
+        if (two_phase) {
         const uint32_t T1 = (A + RS_TILE - 1) / RS_TILE;
         hipLaunchKernelGGL(bwt_flags, dim3(T1), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T1, PK_SHIFT);
         hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T1, w.counters, w.h_counters);
         hipLaunchKernelGGL(bwt_phase2_records, dim3(T1), dim3(256), 0, s, w.key[c], A, g, d_T, w.tile_cnt, T1, w.key[1 - c]);
-        c = 1 - c;
-        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true)));
-      }
-      else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
+          c = 1 - c;
+          CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true)));
+        }
+      } else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
     } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
