@@ -601,11 +601,10 @@ __global__ __launch_bounds__(64) void bz_huff_ops(const uint8_t* __restrict__ in
   }
 }
 
-// rows are addressed through a 1-D grid (a file of tiny member streams has more rows than grid.y allows)
+// grid = (tile groups, rows of a slab): rows come in slabs of <= 65535 (grid.y), and a grid may not exceed 2^32 threads in all
 __global__ __launch_bounds__(256) void bz_mtf_tiles(uint8_t* __restrict__ ops_all, uint32_t ops_stride, const uint32_t* __restrict__ nops_all,
-                                                    uint8_t* __restrict__ pl_all, uint32_t tiles_per_row, uint32_t tiles_used) {
-  const uint32_t groups = (tiles_used + 3u) >> 2;
-  const uint32_t row = blockIdx.x / groups, t = (blockIdx.x - row * groups) * 4u + (threadIdx.x >> 6);
+                                                    uint8_t* __restrict__ pl_all, uint32_t tiles_per_row, uint32_t row0) {
+  const uint32_t row = row0 + blockIdx.y, t = blockIdx.x * 4u + (threadIdx.x >> 6);
   const int lane = lane_id();
   const uint32_t nops = nops_all[row];
   if ((size_t)t * MT_TILE >= nops) return;
@@ -653,8 +652,8 @@ __global__ __launch_bounds__(256) void bz_mtf_compose(const uint32_t* __restrict
 
 __global__ __launch_bounds__(256) void bz_mtf_emit(const uint8_t* __restrict__ q_all, const uint32_t* __restrict__ opoff_all, uint32_t ops_stride,
                                                    const uint32_t* __restrict__ nops_all, const uint8_t* __restrict__ l0_all, const uint8_t* __restrict__ pl_all,
-                                                   uint32_t tiles_per_row, uint32_t tiles_used, uint8_t* __restrict__ tt_all, uint32_t dbuf_size) {
-  const uint32_t row = blockIdx.x / tiles_used, t = blockIdx.x - row * tiles_used;
+                                                   uint32_t tiles_per_row, uint32_t row0, uint8_t* __restrict__ tt_all, uint32_t dbuf_size) {
+  const uint32_t row = row0 + blockIdx.y, t = blockIdx.x;
   const int lane = lane_id();
   const uint32_t nops = nops_all[row];
   if ((size_t)t * MT_TILE >= nops && t) return;
@@ -1085,7 +1084,13 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   uint8_t* d_al = d_raw + (S->up_lo & 3u);
   S->d_in = d_al - S->up_lo;
   if (hipMemcpyAsync(d_al, J->in + S->up_lo, up_n, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(d_count, 0, 64, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
-  if (S->hi > S->lo) hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((S->hi - S->lo + 255) / 256)), dim3(256), 0, s, S->d_in, S->lo, S->hi, S->up_hi, d_cand, cand_cap, d_count);
+  auto launch_scan = [&]() {                                            // (slabs: a grid may not exceed 2^32 threads)
+    for (uint64_t b0 = S->lo; b0 < S->hi; b0 += 1ull << 31) {
+      const uint64_t b1 = std::min<uint64_t>(S->hi, b0 + (1ull << 31));
+      hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((b1 - b0 + 255) / 256)), dim3(256), 0, s, S->d_in, b0, b1, S->up_hi, d_cand, cand_cap, d_count);
+    }
+  };
+  launch_scan();
   uint32_t ncand = 0;
   if (hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
   if (ncand > cand_cap) {                                             // more magics than planned for (many tiny member streams): scan again with room for all
@@ -1093,7 +1098,7 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     cand_cap = ncand;
     if ((rc = S->take((void**)&d_cand, sizeof(Cand) * cand_cap)) != 0) { S->rc = rc; return; }
     if (hipMemsetAsync(d_count, 0, 64, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
-    hipLaunchKernelGGL(bz_magic_scan, dim3((unsigned)((S->hi - S->lo + 255) / 256)), dim3(256), 0, s, S->d_in, S->lo, S->hi, S->up_hi, d_cand, cand_cap, d_count);
+    launch_scan();
     if (hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
     if (ncand > cand_cap) { S->rc = CJS_E_HIP; return; }
   }
@@ -1133,11 +1138,13 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     for (auto& b : S->bos) if (!b.err && b.count > maxc) maxc = b.count;
     if (nrows) {
       const uint32_t tiles_used = std::min<uint32_t>(maxc / MT_TILE + 1u, tiles_per_row);
-      const uint64_t g1 = (uint64_t)nrows * ((tiles_used + 3u) / 4u), g3 = (uint64_t)nrows * tiles_used;
-      if (g3 >= 0x7FFFFFFFull) { S->rc = CJS_E_UNSUPPORTED; return; }
-      hipLaunchKernelGGL(bz_mtf_tiles, dim3((unsigned)g1), dim3(256), 0, s, d_ops, ops_stride, d_nops, d_pl, tiles_per_row, tiles_used);
+      // slabs of rows: grid.y <= 65535 and grid.x * grid.y * 256 threads < 2^32 (a larger launch is cut short without an error)
+      const uint32_t slab = std::min<uint32_t>(65535u, std::max<uint32_t>(1u, (1u << 23) / tiles_used));
+      for (uint32_t r0 = 0; r0 < nrows; r0 += slab)
+        hipLaunchKernelGGL(bz_mtf_tiles, dim3((tiles_used + 3u) / 4u, std::min(slab, nrows - r0)), dim3(256), 0, s, d_ops, ops_stride, d_nops, d_pl, tiles_per_row, r0);
       hipLaunchKernelGGL(bz_mtf_compose, dim3(nrows), dim3(256), 0, s, d_nops, d_l0, d_pl, tiles_per_row);
-      hipLaunchKernelGGL(bz_mtf_emit, dim3((unsigned)g3), dim3(256), 0, s, d_ops, d_opoff, ops_stride, d_nops, d_l0, d_pl, tiles_per_row, tiles_used, S->d_tt, dsz);
+      for (uint32_t r0 = 0; r0 < nrows; r0 += slab)
+        hipLaunchKernelGGL(bz_mtf_emit, dim3(tiles_used, std::min(slab, nrows - r0)), dim3(256), 0, s, d_ops, d_opoff, ops_stride, d_nops, d_l0, d_pl, tiles_per_row, r0, S->d_tt, dsz);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
     }
     S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops);
@@ -1264,7 +1271,7 @@ void dec_phase_c(DecJob* J, DecShare* S) {
     if (!rc && hipMemcpyAsync(crcs.data(), d_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
     if (!rc && J->host && obytes && hipMemcpyAsync(J->host + o0, d_out, (size_t)obytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
     if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc) for (uint32_t k = 0; k < nb; k++) if (crcs[k] != blk[k].crc) {                                   // Bad block CRC (:1756-1761)
+    if (!rc) for (uint32_t k = 0; k < nb; k++) if (crcs[k] != blk[k].crc) {                    // Bad block CRC (:1756-1761)
       snprintf(S->detail, sizeof S->detail, "Bad block CRC (got %x expected %x)", crcs[k], blk[k].crc);
       if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block %zu: Bad block CRC (got %08x expected %08x) out_len %u\n", b0 + k, crcs[k], blk[k].crc, blk[k].out_len);
       rc = CJS_E_DATA_ERROR; break;

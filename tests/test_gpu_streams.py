@@ -458,3 +458,20 @@ def test_1gib_goldens_compress_and_decompress(hip):
     rc, out = hip.bwtc_compress(data, 9)
     assert rc == 0, hip.L.cjs_strerror(rc)
     assert out.size == wcase["out_len"] and support.sha256(out) == wcase["out_sha256"]
+
+
+@pytest.mark.slow
+def test_bzip2_round_trip_above_4gib(hip):
+    # every size_t path end to end: compress takes block ranges one after the other (CJS_CHUNK_BYTES), decompress takes
+    # batches of blocks; 4910 blocks x 3516 tiles is also more workgroups x threads than one launch may carry (2^32), so
+    # the decoder's stage kernels must go in slabs.  The first GiB of the input is the 1 GiB golden's input, hence the
+    # compressed stream must start with that golden's blocks (all but the golden's last, partial block).
+    n = (1 << 32) + 123456789
+    data = recipes.textgen(n, 1)
+    want = support.sha256(data)
+    rc, comp = hip.bzip2_compress(data, 9)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    hip.L.cjs_trim()
+    rc, back = hip.bzip2_decompress(comp)
+    assert rc == 0, (hip.L.cjs_strerror(rc), hip.last_error_detail())
+    assert back.size == n and support.sha256(back) == want
