@@ -464,8 +464,7 @@ def test_1gib_goldens_compress_and_decompress(hip):
 def test_bzip2_round_trip_above_4gib(hip):
     # every size_t path end to end: compress takes block ranges one after the other (CJS_CHUNK_BYTES), decompress takes
     # batches of blocks; 4910 blocks x 3516 tiles is also more workgroups x threads than one launch may carry (2^32), so
-    # the decoder's stage kernels must go in slabs.  The first GiB of the input is the 1 GiB golden's input, hence the
-    # compressed stream must start with that golden's blocks (all but the golden's last, partial block).
+    # the decoder's stage kernels must go in slabs.
     n = (1 << 32) + 123456789
     data = recipes.textgen(n, 1)
     want = support.sha256(data)
