@@ -115,13 +115,23 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
   uint32_t tb0 = 0;
   if (GEN) tb0 = gen_stage(gs, sg, t, tb);
   __syncthreads();
+  if (GEN) {
 #pragma unroll 4
-  for (int it = 0; it < 16; it++) {
-    const uint32_t loc = (uint32_t)it * 256 + tid;
-    if (loc < t.nvalid) {
-      const uint64_t k = GEN ? gen_key(gs, sg, t, tb, tb0, loc) : (uint64_t)keys[t.base + loc];
-      atomicAdd(&h[w][(uint32_t)(k >> shift) & 255u], 1u);
+    for (int it = 0; it < 16; it++) {
+      const uint32_t loc = (uint32_t)it * 256 + tid;
+      if (loc < t.nvalid) atomicAdd(&h[w][(uint32_t)(gen_key(gs, sg, t, tb, tb0, loc) >> shift) & 255u], 1u);
     }
+  } else if (t.nvalid) {
+    // all sixteen loads are issued before the first atomic (written as one loop the compiler waits for each load in turn)
+    K k[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint32_t loc = (uint32_t)it * 256 + tid;
+      k[it] = keys[t.base + (loc < t.nvalid ? loc : t.nvalid - 1u)];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      if ((uint32_t)it * 256 + tid < t.nvalid) atomicAdd(&h[w][(uint32_t)((uint64_t)k[it] >> shift) & 255u], 1u);
   }
   __syncthreads();
   hist[(size_t)tile * 256 + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
@@ -173,11 +183,39 @@ __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
   return peers;
 }
 
-template <typename K, bool GEN, bool NOVAL>
+// One ranking step of a wave: the number of keys with this lane's digit that the wave has seen before this lane's key (earlier
+// steps, then lower lanes of this step); wc = the wave's 256 running digit counts.
+// ML (default): the peer mask comes out of LDS -- every lane ORs its lane bit into the digit's 64-bit word of wm (the wave's
+// 256 mask words, all zero between steps; LDS runs the DS instructions of a wave in order), reads the word back, and the first
+// lane of each digit clears it again: 2 DS + ~10 VALU instructions where the eight-ballot match costs ~60 VALU (a wave64 VALU
+// instruction holds its SIMD for 4 cycles, which made the ranking, not the memory traffic, the longest part of a radix pass).
+template <bool ML>
+__device__ __forceinline__ uint32_t rank_step(uint32_t d, uint32_t* __restrict__ wc, uint64_t* __restrict__ wm, uint64_t lanebit) {
+  uint64_t peers;
+  if (ML) {
+    __hip_atomic_fetch_or(&wm[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    peers = __hip_atomic_load(&wm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  } else peers = match_any8(d);
+  const uint32_t prior = wc[d];
+  const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+  __builtin_amdgcn_wave_barrier();
+  if (r == 0) {
+    wc[d] = prior + (uint32_t)__popcll(peers);
+    if (ML) __hip_atomic_store(&wm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return prior + r;
+}
+
+template <typename K, bool GEN, bool NOVAL, bool ML>
 __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                   K* __restrict__ kout, uint32_t* __restrict__ vout, SegGeom sg, GenSrc gs, int shift,
                                                   const uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ bintot) {
-  __shared__ K skey[RS_TILE + 2];
+  __shared__ __attribute__((aligned(16))) K skey[RS_TILE + 2];
   __shared__ uint32_t sval[NOVAL ? 1 : RS_TILE];
   __shared__ uint32_t wcnt[4][256];
   __shared__ uint32_t goff[256];
@@ -212,18 +250,16 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
     }
   }
   __syncthreads();
-  const uint64_t lt = (1ull << lane) - 1ull;
+  uint64_t* wm = reinterpret_cast<uint64_t*>(skey) + w * 256;        // mask words of this wave (skey is free until the ranking is done)
+  if (ML) {
 #pragma unroll
-  for (int s = 0; s < 16; s++) {
-    const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
-    const uint64_t peers = match_any8(d);
-    const uint32_t prior = wcnt[w][d];
-    const uint32_t r = (uint32_t)__popcll(peers & lt);
-    rk[s] = prior + r;
-    __builtin_amdgcn_wave_barrier();
-    if (r == 0) wcnt[w][d] = prior + (uint32_t)__popcll(peers);
+    for (int i = 0; i < 4; i++) wm[i * 64 + lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  const uint64_t lanebit = 1ull << lane;
+#pragma unroll
+  for (int s = 0; s < 16; s++) rk[s] = rank_step<ML>((uint32_t)(k[s] >> shift) & 255u, wcnt[w], wm, lanebit);
   __syncthreads();
   {
     const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
@@ -308,31 +344,59 @@ __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint3
   const uint32_t tile = xcd_tile(blockIdx.x, T);
   if (tile >= T) return;
   const uint64_t base = (uint64_t)tile * RS_TILE;
-#pragma unroll 4
+  const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
+  // three batches of sixteen independent loads each (streams, then the rank gathers, then the stores): as one loop the
+  // compiler waits for every gather before it issues the next
+  uint32_t p16[16], v16[16], g16[16], kk[16];
+#pragma unroll
   for (int it = 0; it < 16; it++) {
-    const uint64_t a = base + (uint32_t)it * 256 + threadIdx.x;
-    if (a < A) {
-      const uint32_t blk = __builtin_nontemporal_load(pos + a) / g.stride, n = blk_len(g, blk);
-      uint64_t j = (uint64_t)__builtin_nontemporal_load(val + a) + h;
-      uint32_t kk;
-      if (cyclic) { if (j >= n) j %= n; kk = R[(size_t)blk * g.stride + j] + 1u; }
-      else kk = j < n ? R[(size_t)blk * g.stride + j] + 1u : 0u;
-      __builtin_nontemporal_store(((uint64_t)__builtin_nontemporal_load(gord + a) << 20) | kk, key + a);
-    }
+    const uint32_t e = (uint32_t)it * 256 + threadIdx.x;
+    const uint64_t a = base + (e < nvalid ? e : nvalid - 1u);
+    p16[it] = __builtin_nontemporal_load(pos + a); v16[it] = __builtin_nontemporal_load(val + a); g16[it] = __builtin_nontemporal_load(gord + a);
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t blk = p16[it] / g.stride, n = blk_len(g, blk);
+    uint32_t j = v16[it] + h;                  // (both below 2^31)
+    if (cyclic) { if (j >= n) j %= n; }
+    const bool past = !cyclic && j >= n;
+    kk[it] = R[(size_t)blk * g.stride + (past ? 0 : j)] + 1u;
+    if (past) kk[it] = 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256 + threadIdx.x;
+    if (e < nvalid) __builtin_nontemporal_store(((uint64_t)g16[it] << 20) | kk[it], key + base + e);
   }
 }
 
 // per 4096-tile: #surviving elements, #surviving group heads, (last new-head index)+1
 __global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ key, uint32_t A, uint32_t* __restrict__ tile_cnt, uint32_t T, int gshift) {
+  __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint32_t sm[4];
   const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+  const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
   uint32_t surv = 0, heads = 0, last = 0;
+  // the tile's keys go through LDS so that every global load is issued up front (neighbours come from LDS, not from three
+  // loads per element that the compiler waits for one by one)
+  uint64_t k[16];
+#pragma unroll
   for (int it = 0; it < 16; it++) {
-    const uint64_t a = base + (uint32_t)it * 256 + threadIdx.x;
-    if (a < A) {
-      const uint64_t k = key[a] >> gshift;            // packed round-1 records: the low bits are the position
-      const bool nh = a == 0 || (key[a - 1] >> gshift) != k;
-      const bool nx = a + 1 == A || (key[a + 1] >> gshift) != k;
+    const uint32_t loc = (uint32_t)it * 256 + threadIdx.x;
+    k[it] = key[base + (loc < nvalid ? loc : nvalid - 1u)] >> gshift;            // packed round-1 records: the low bits are the position
+  }
+  if (threadIdx.x == 0) sk[0] = base ? key[base - 1] >> gshift : 0;
+  if (threadIdx.x == 64) sk[RS_TILE + 1] = base + RS_TILE < A ? key[base + RS_TILE] >> gshift : 0;
+#pragma unroll
+  for (int it = 0; it < 16; it++) sk[1u + (uint32_t)it * 256 + threadIdx.x] = k[it];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t loc = (uint32_t)it * 256 + threadIdx.x;
+    const uint64_t a = base + loc;
+    if (loc < nvalid) {
+      const bool nh = a == 0 || sk[loc] != k[it];
+      const bool nx = a + 1 == A || sk[loc + 2] != k[it];
       const bool single = nh && nx;
       surv += !single;
       heads += nh && !single;
@@ -397,14 +461,30 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint64_t base = (uint64_t)tile * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
-#pragma unroll 4
-  for (int it = 0; it < 16; it++) {
-    const uint32_t e = (uint32_t)it * 256u + tid;
-    sk[e + 1] = e < nvalid ? __builtin_nontemporal_load(key + base + e) : ~0ull;     // streamed once: keep the L2 for R
-  }
-  if (tid == 0) {
-    sk[0] = base ? key[base - 1] : ~0ull;
-    sk[RS_TILE + 1] = base + RS_TILE < A ? key[base + RS_TILE] : ~0ull;
+  // every streaming load of the tile is issued up front (one loop of load + LDS store makes the compiler wait per load)
+  uint32_t p16[FIRST ? 1 : 16], v16[PACKED ? 1 : 16];
+  {
+    uint64_t k16[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint32_t e = (uint32_t)it * 256u + tid;
+      k16[it] = __builtin_nontemporal_load(key + base + (e < nvalid ? e : nvalid - 1u));     // streamed once: keep the L2 for R
+    }
+    if (!FIRST) {
+#pragma unroll
+      for (int it = 0; it < 16; it++) { const uint32_t e = (uint32_t)it * 256u + tid; p16[it] = __builtin_nontemporal_load(pos + base + (e < nvalid ? e : nvalid - 1u)); }
+    }
+    if (!PACKED) {
+#pragma unroll
+      for (int it = 0; it < 16; it++) { const uint32_t e = (uint32_t)it * 256u + tid; v16[it] = __builtin_nontemporal_load(val + base + (e < nvalid ? e : nvalid - 1u)); }
+    }
+    if (tid == 0) sk[0] = base ? key[base - 1] : ~0ull;
+    if (tid == 64) sk[RS_TILE + 1] = base + RS_TILE < A ? key[base + RS_TILE] : ~0ull;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint32_t e = (uint32_t)it * 256u + tid;
+      sk[e + 1] = e < nvalid ? k16[it] : ~0ull;
+    }
   }
   __syncthreads();
   constexpr int GS = PACKED ? PK_SHIFT : 0;      // packed records: the group key sits above the position bits
@@ -440,7 +520,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   __syncthreads();
   const uint32_t sbase = tile_cnt[tile], hbase = tile_cnt[T + tile], carry = tile_cnt[2 * (size_t)T + tile];
   const uint64_t lt = (1ull << lane) - 1ull, le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-#pragma unroll 4
+#pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
     if (e < nvalid) {
@@ -458,8 +538,8 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
         head_a = carry - 1u;
         if (!FIRST) keeps_rank = head_a == 0 || (key[head_a] >> 20) != (key[head_a - 1] >> 20);
       }
-      const uint32_t p = FIRST ? (uint32_t)a : __builtin_nontemporal_load(pos + a);
-      const uint32_t vv = PACKED ? ((uint32_t)sk[e + 1] & PK_POS_MASK) : __builtin_nontemporal_load(val + a);
+      const uint32_t p = FIRST ? (uint32_t)a : p16[FIRST ? 0 : it];
+      const uint32_t vv = PACKED ? ((uint32_t)sk[e + 1] & PK_POS_MASK) : v16[PACKED ? 0 : it];
       const uint32_t blk = p / g.stride;
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
       if (!keeps_rank && (hm_.halves <= 1 || (uint32_t)(vv >= hsplit) == half)) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
@@ -502,13 +582,26 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
   const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
   const uint32_t L = (uint32_t)(we - wb);
   uint64_t r[16];
+  uint32_t pv[16];
+  // every global load of the window (keys and suffixes) is issued before the first LDS store: written as one loop the
+  // compiler waits for each load in turn, sixteen memory round trips instead of one
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t x = (uint32_t)it * 256u + tid;
-    r[it] = x < L ? key[wb + x] : ~0ull;
-    gk[x] = (uint32_t)(r[it] >> 20);
+    r[it] = key[wb + (x < L ? x : L - 1u)];
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t x = (uint32_t)it * 256u + tid;
+    pv[it] = val[wb + (x < L ? x : L - 1u)];
   }
   const uint32_t gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t x = (uint32_t)it * 256u + tid;
+    if (x >= L) r[it] = ~0ull;
+    gk[x] = (uint32_t)(r[it] >> 20);
+  }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < 16; it++) {
@@ -559,7 +652,7 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     any_medium |= medium ? 1 : 0;
     const uint64_t k = r[it];
     go[it] = (uint32_t)(k >> 20);
-    const uint64_t v = owned ? (uint64_t)val[wb + x] : 0ull;
+    const uint64_t v = owned ? (uint64_t)pv[it] : 0ull;
     r[it] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
                   : (((uint64_t)x << 52) | (0xFFFFFull << 32));
   }
@@ -649,6 +742,7 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
 // composite (4 passes of 8 bits, wave64 match-any ranking, one LDS staging array) is then a permutation INSIDE every owned
 // group: exactly h slots carry a composite below (h << 20), so the members of the group headed at h land on [h, h + size).
 // The cost does not depend on the group sizes (the counting / bitonic version above degrades with them).
+template <bool ML>
 __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
                                                            uint8_t* __restrict__ dflag) {
   __shared__ uint64_t se[TS_WIN];                // (composite << 32) | suffix: staging of a pass
@@ -662,13 +756,26 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
   const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
   const uint32_t L = (uint32_t)(we - wb);
   // slot of (wave w, step s, lane): w * 1024 + s * 64 + lane -- array order = (w, s, lane) order, which the stable ranking needs
-  uint32_t rk20[16], go[16];
+  uint32_t rk20[16], go[16], pv[16];
+  {
+    uint64_t k[16];                              // every load is issued before the first LDS store
 #pragma unroll
-  for (int s = 0; s < 16; s++) {
-    const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
-    const uint64_t k = x < L ? key[wb + x] : ~0ull;
-    go[s] = (uint32_t)(k >> 20); rk20[s] = (uint32_t)k & 0xFFFFFu;
-    gk[x] = go[s];
+    for (int s = 0; s < 16; s++) {
+      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+      k[s] = key[wb + (x < L ? x : L - 1u)];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+      pv[s] = val[wb + (x < L ? x : L - 1u)];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+      if (x >= L) k[s] = ~0ull;
+      go[s] = (uint32_t)(k[s] >> 20); rk20[s] = (uint32_t)k[s] & 0xFFFFFu;
+      gk[x] = go[s];
+    }
   }
   const uint32_t gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
   __syncthreads();
@@ -694,7 +801,7 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
     wlast[lane] = el; wnext[lane] = en;
   }
   __syncthreads();
-  uint32_t comp[16], pv[16];
+  uint32_t comp[16];
   uint32_t ownm = 0;
 #pragma unroll
   for (int s = 0; s < 16; s++) {
@@ -710,26 +817,22 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
     if (owned && dflag) dflag[wb + x] = 0;
     ownm |= owned ? 1u << s : 0u;
     comp[s] = owned ? (((uint32_t)hx << 20) | rk20[s]) : (x << 20);
-    pv[s] = owned ? val[wb + x] : 0u;
+    if (!owned) pv[s] = 0u;
   }
   if (!__syncthreads_or((int)ownm)) return;      // also: gk (aliasing se) is dead from here
-  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint64_t lanebit = 1ull << lane;
+  uint64_t* wm = se + w * 256;                   // mask words of this wave: the staging array is dead while a pass ranks
 #pragma unroll 1
   for (int shift = 0; shift < 32; shift += 8) {
     for (int i = tid; i < 1024; i += 256) (&wcnt[0][0])[i] = 0;
+    if (ML) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) wm[i * 64 + lane] = 0;
+    }
     __syncthreads();
     uint32_t rk[16];
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const uint32_t d = (comp[s] >> shift) & 255u;
-      const uint64_t peers = match_any8(d);
-      const uint32_t prior = wcnt[w][d];
-      const uint32_t r = (uint32_t)__popcll(peers & lt);
-      rk[s] = prior + r;
-      __builtin_amdgcn_wave_barrier();
-      if (r == 0) wcnt[w][d] = prior + (uint32_t)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-    }
+    for (int s = 0; s < 16; s++) rk[s] = rank_step<ML>((comp[s] >> shift) & 255u, wcnt[w], wm, lanebit);
     __syncthreads();
     {
       const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
@@ -819,12 +922,29 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint64_t base = (uint64_t)tile * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
-#pragma unroll 4
+  uint64_t k16[16];                              // all loads first (see bwt_apply)
+#pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
-    sk[e + 1] = e < nvalid ? __builtin_nontemporal_load(key + base + e) : ~0ull;
+    k16[it] = __builtin_nontemporal_load(key + base + (e < nvalid ? e : nvalid - 1u));
   }
   if (tid == 0) sk[0] = base ? key[base - 1] : ~0ull;
+  // the two leading bytes of every record's suffix: gathers from the block text (L2), independent of everything below
+  uint32_t b01[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    const uint32_t a = (uint32_t)base + (e < nvalid ? e : nvalid - 1u);
+    const uint32_t blk = a / g.stride, n = blk_len(g, blk);
+    const uint32_t p = (uint32_t)k16[it] & PK_POS_MASK;
+    const uint8_t* t = T + (size_t)blk * g.stride;
+    b01[it] = ((uint32_t)t[p] << 8) | t[p + 1 < n ? p + 1 : 0];
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t e = (uint32_t)it * 256u + tid;
+    sk[e + 1] = e < nvalid ? k16[it] : ~0ull;
+  }
   __syncthreads();
 #pragma unroll 4
   for (int it = 0; it < 16; it++) {
@@ -845,7 +965,7 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
   __syncthreads();
   const uint32_t carry = tile_cnt[2 * (size_t)Tn + tile];
   const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-#pragma unroll 4
+#pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
     if (e < nvalid) {
@@ -853,13 +973,10 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
       const uint64_t hm = m_nh[wi] & le;
       const uint32_t head_a = hm ? (uint32_t)base + (uint32_t)wi * 64u + 63u - (uint32_t)__builtin_clzll(hm) : wp_head[wi] ? (uint32_t)base + wp_head[wi] - 1u : carry - 1u;
       const uint32_t a = (uint32_t)base + e;
-      const uint32_t blk = a / g.stride, n = blk_len(g, blk);
-      const uint64_t k = sk[e + 1];
-      const uint32_t p = (uint32_t)k & PK_POS_MASK;
-      const uint8_t* t = T + (size_t)blk * g.stride;
-      const uint32_t b0 = t[p], b1 = t[p + 1 < n ? p + 1 : 0];
+      const uint32_t blk = a / g.stride;
+      const uint64_t k = k16[it];
       const uint32_t r1 = head_a - blk * g.stride;
-      __builtin_nontemporal_store(((uint64_t)b0 << 56) | ((uint64_t)b1 << 48) | ((uint64_t)r1 << 28) | (k & ((1ull << (PK_SHIFT + 1)) - 1ull)), out + a);
+      __builtin_nontemporal_store(((uint64_t)b01[it] << 48) | ((uint64_t)r1 << 28) | (k & ((1ull << (PK_SHIFT + 1)) - 1ull)), out + a);
     }
   }
 }
@@ -888,29 +1005,40 @@ __global__ __launch_bounds__(256) void bwt_emit(const uint8_t* __restrict__ T, G
   if (cyclic && (((uintptr_t)U | (uintptr_t)SA) & 15u) == 0) {
     // U is one flat array in sorted-position order (u[p] of block blk is U[blk*stride + p]): four positions per lane,
     // one 16-byte load of SA, four byte gathers from the block text, one aligned 32-bit store
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if ((uint64_t)(tile + 1) * RS_TILE <= M) {       // whole tile: four SA loads, then sixteen byte gathers, then four stores
+      u32x4 s4[4];
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const uint64_t a0 = (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u;
-      if (a0 >= M) break;
-      if (a0 + 4 <= M) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 s4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(SA + a0));
-        const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
-        uint32_t outw = 0;
+      for (int it = 0; it < 4; it++)
+        s4[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(SA + (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u));
+      uint32_t outw[4];
+      const uint32_t t0 = tile * RS_TILE, blk0 = t0 / g.stride;          // (M is 32 bits wide: so is every position)
+      const uint64_t nextb = (uint64_t)(blk0 + 1) * g.stride;           // a tile touches two blocks at most when stride >= RS_TILE
+      const bool two = g.stride >= RS_TILE;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const uint32_t a0 = t0 + ((uint32_t)it * 256 + threadIdx.x) * 4u;
+        const uint32_t sv[4] = {s4[it].x, s4[it].y, s4[it].z, s4[it].w};
+        uint32_t b[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const uint64_t a = a0 + j;
-          const uint32_t blk = (uint32_t)(a / g.stride), n = blk_len(g, blk);
-          const uint8_t* t = T + (size_t)blk * g.stride;
-          outw |= (uint32_t)t[sv[j] ? sv[j] - 1 : n - 1] << (8 * j);
+          const uint32_t a = a0 + j;
+          const uint32_t blk = two ? blk0 + (a >= nextb ? 1u : 0u) : a / g.stride, n = blk_len(g, blk);
+          b[j] = T[(size_t)blk * g.stride + (sv[j] ? sv[j] - 1 : n - 1)];
         }
-        *reinterpret_cast<uint32_t*>(U + a0) = outw;
-      } else {
-        for (uint64_t a = a0; a < M; a++) {
-          const uint32_t blk = (uint32_t)(a / g.stride), n = blk_len(g, blk);
-          const uint32_t s = SA[a];
-          U[a] = T[(size_t)blk * g.stride + (s ? s - 1 : n - 1)];
-        }
+        outw[it] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; it++)
+        *reinterpret_cast<uint32_t*>(U + (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u) = outw[it];
+      return;
+    }
+    for (int it = 0; it < 4; it++) {
+      const uint64_t a0 = (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u;
+      for (uint64_t a = a0; a < a0 + 4 && a < M; a++) {
+        const uint32_t blk = (uint32_t)(a / g.stride), n = blk_len(g, blk);
+        const uint32_t s = SA[a];
+        U[a] = T[(size_t)blk * g.stride + (s ? s - 1 : n - 1)];
       }
     }
     return;
@@ -984,6 +1112,12 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
   }
 };
 
+// CJS_MATCH=valu: the eight-ballot peer match instead of the LDS mask words (A/B)
+static bool match_lds() {
+  static const bool v = [] { const char* e = getenv("CJS_MATCH"); return !(e && !strcmp(e, "valu")); }();
+  return v;
+}
+
 template <typename K>
 static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
                         LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr, bool noval = false) {
@@ -1009,13 +1143,15 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
       }
     }
     if (lt) lt->begin(s, n);
-    if (noval) {
-      if (first_gen) hipLaunchKernelGGL((rs_scatter<K, true, true>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, *gen, shift, w.hist, T, w.bintot);
-      else hipLaunchKernelGGL((rs_scatter<K, false, true>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, g0, shift, w.hist, T, w.bintot);
+#define RS_SCATTER(GEN_, NOVAL_, ML_, G_) hipLaunchKernelGGL((rs_scatter<K, GEN_, NOVAL_, ML_>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, G_, shift, w.hist, T, w.bintot)
+    if (match_lds()) {
+      if (noval) { if (first_gen) RS_SCATTER(true, true, true, *gen); else RS_SCATTER(false, true, true, g0); }
+      else { if (first_gen) RS_SCATTER(true, false, true, *gen); else RS_SCATTER(false, false, true, g0); }
     } else {
-      if (first_gen) hipLaunchKernelGGL((rs_scatter<K, true, false>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, *gen, shift, w.hist, T, w.bintot);
-      else hipLaunchKernelGGL((rs_scatter<K, false, false>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, g0, shift, w.hist, T, w.bintot);
+      if (noval) { if (first_gen) RS_SCATTER(true, true, false, *gen); else RS_SCATTER(false, true, false, g0); }
+      else { if (first_gen) RS_SCATTER(true, false, false, *gen); else RS_SCATTER(false, false, false, g0); }
     }
+#undef RS_SCATTER
     if (lt) lt->end(s);
     cur = 1 - cur;
   }
@@ -1036,7 +1172,8 @@ template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uin
 static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag, uint32_t ngroups) {
   static const int forced = !getenv("CJS_TILE_SORT") ? 0 : !strcmp(getenv("CJS_TILE_SORT"), "radix") ? 1 : 2;
   const bool radix = forced ? forced == 1 : (ngroups && A / ngroups >= 5);
-  if (radix) hipLaunchKernelGGL(bwt_tile_sort_radix, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
+  if (radix && match_lds()) hipLaunchKernelGGL(bwt_tile_sort_radix<true>, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
+  else if (radix) hipLaunchKernelGGL(bwt_tile_sort_radix<false>, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
   else hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
 }
 // One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.
