@@ -100,16 +100,23 @@ __device__ __forceinline__ uint64_t gen_key(const GenSrc& gs, const SegGeom& sg,
 }
 
 // Per-tile digit counts, tile-major: hist[tile * 256 + digit] (one coalesced 1 KB row per workgroup; the digit-major
-// layout of round 1 cost a 64-byte memory transaction per 4-byte counter on both sides).  One sub-histogram per wave.
-// (Eight sub-histograms per wave picked by lane & 7 against the same-address serialisation of skewed text digits were
-// measured slower, 283 vs 235 us per 100 M keys: zeroing and folding 32 KB of LDS per tile costs more than it saves.)
+// layout of round 1 cost a 64-byte memory transaction per 4-byte counter on both sides).
+// LDS atomics of one instruction that meet in one address OR in one bank are done one after the other, and text digits
+// are skewed (a fifth of the lanes carry a space; a pass over a sorted byte has all 64 lanes on one counter): each wave
+// counts into HR = 8 copies of its histogram picked by lane & 7 and laid out digit * 8 + copy, so the copies of a digit
+// sit in eight different banks.  100 M keys, MI355X: 237 us (text digit) / 344 us (sorted digit) with one copy per wave;
+// copies 1 KB apart (same bank) 141 / 190 us with two and slower again with more; interleaved copies 135 us for both,
+// against 125 us for the same loads without any atomic.
+constexpr int HR = 8;
 template <typename K, bool GEN>
 __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGeom sg, GenSrc gs, int shift,
                                                uint32_t* __restrict__ hist, uint32_t T) {
-  __shared__ uint32_t h[4][256];
+  __shared__ uint32_t h[4 * 256 * HR];
   __shared__ __attribute__((aligned(16))) uint8_t tb[GEN ? RS_TILE + GEN_PAD + 16 : 16];
-  const int tid = threadIdx.x, w = tid >> 6;
-  for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
+  const int tid = threadIdx.x;
+  uint32_t* hw = h + (tid >> 6) * 256 * HR + (tid & (HR - 1));          // this lane's copy in this wave's histogram
+#pragma unroll
+  for (int i = 0; i < 4 * HR; i++) h[i * 256 + tid] = 0;
   const uint32_t tile = blockIdx.x;
   const TileRef t = tile_ref(sg, tile);
   uint32_t tb0 = 0;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
 #pragma unroll 4
     for (int it = 0; it < 16; it++) {
       const uint32_t loc = (uint32_t)it * 256 + tid;
-      if (loc < t.nvalid) atomicAdd(&h[w][(uint32_t)(gen_key(gs, sg, t, tb, tb0, loc) >> shift) & 255u], 1u);
+      if (loc < t.nvalid) atomicAdd(&hw[((uint32_t)(gen_key(gs, sg, t, tb, tb0, loc) >> shift) & 255u) * HR], 1u);
     }
   } else if (t.nvalid) {
     // all sixteen loads are issued before the first atomic (written as one loop the compiler waits for each load in turn)
@@ -131,10 +138,15 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
     }
 #pragma unroll
     for (int it = 0; it < 16; it++)
-      if ((uint32_t)it * 256 + tid < t.nvalid) atomicAdd(&h[w][(uint32_t)((uint64_t)k[it] >> shift) & 255u], 1u);
+      if ((uint32_t)it * 256 + tid < t.nvalid) atomicAdd(&hw[((uint32_t)((uint64_t)k[it] >> shift) & 255u) * HR], 1u);
   }
   __syncthreads();
-  hist[(size_t)tile * 256 + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < HR; r++) sum += h[i * 256 * HR + tid * HR + r];
+  hist[(size_t)tile * 256 + tid] = sum;
 }
 
 // one workgroup per segment: exclusive scan over the segment's tiles of every digit's count (thread = digit; the rows are
@@ -172,46 +184,38 @@ __global__ __launch_bounds__(256) void rs_scan_chunk_apply(uint32_t* __restrict_
   for (uint32_t t = t0; t < t1; t++) { const uint32_t v = hist[(size_t)t * 256 + threadIdx.x]; hist[(size_t)t * 256 + threadIdx.x] = carry; carry += v; }
 }
 
+// lanes of the wave that carry the same 8-bit digit.  Per bit: m = the bit spread over a word (v_bfe_i32), one ballot, and
+// the lanes whose bit differs from mine are ballot ^ m, folded into the running OR by one v_bitop3 per half (q | (m ^ bal) =
+// table 0xde): four VALU instructions per bit (the select form took nine).
 __device__ __forceinline__ uint64_t match_any8(uint32_t d) {
-  uint64_t peers = ~0ull;
+  uint32_t qlo = 0, qhi = 0;
 #pragma unroll
   for (int b = 0; b < 8; b++) {
-    const bool bit = (d >> b) & 1u;
-    const uint64_t bal = __ballot(bit);
-    peers &= bit ? bal : ~bal;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);      // 0 or ~0
+    const uint64_t bal = __ballot(m != 0);
+    qlo = __builtin_amdgcn_bitop3_b32(m, qlo, (uint32_t)bal, 0xde);
+    qhi = __builtin_amdgcn_bitop3_b32(m, qhi, (uint32_t)(bal >> 32), 0xde);
   }
-  return peers;
+  return ~(((uint64_t)qhi << 32) | qlo);
 }
 
 // One ranking step of a wave: the number of keys with this lane's digit that the wave has seen before this lane's key (earlier
 // steps, then lower lanes of this step); wc = the wave's 256 running digit counts.
-// ML (default): the peer mask comes out of LDS -- every lane ORs its lane bit into the digit's 64-bit word of wm (the wave's
-// 256 mask words, all zero between steps; LDS runs the DS instructions of a wave in order), reads the word back, and the first
-// lane of each digit clears it again: 2 DS + ~10 VALU instructions where the eight-ballot match costs ~60 VALU (a wave64 VALU
-// instruction holds its SIMD for 4 cycles, which made the ranking, not the memory traffic, the longest part of a radix pass).
-template <bool ML>
-__device__ __forceinline__ uint32_t rank_step(uint32_t d, uint32_t* __restrict__ wc, uint64_t* __restrict__ wm, uint64_t lanebit) {
-  uint64_t peers;
-  if (ML) {
-    __hip_atomic_fetch_or(&wm[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    peers = __hip_atomic_load(&wm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  } else peers = match_any8(d);
+// (Measured and dropped: taking the peer mask out of LDS instead of eight ballots -- every lane ORs its lane bit into the
+// digit's 64-bit word, reads it back, the first lane clears it: 15 VALU + 5 DS instructions instead of ~70 VALU, bit-exact,
+// but same-address LDS atomics are done one lane after the other and text digits put a dozen lanes on one word:
+// rs_scatter 345 vs 320 us, tile sorter 1.07 ms both ways.)
+__device__ __forceinline__ uint32_t rank_step(uint32_t d, uint32_t* __restrict__ wc) {
+  const uint64_t peers = match_any8(d);
   const uint32_t prior = wc[d];
   const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
   __builtin_amdgcn_wave_barrier();
-  if (r == 0) {
-    wc[d] = prior + (uint32_t)__popcll(peers);
-    if (ML) __hip_atomic_store(&wm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (r == 0) wc[d] = prior + (uint32_t)__popcll(peers);
   __builtin_amdgcn_wave_barrier();
   return prior + r;
 }
 
-template <typename K, bool GEN, bool NOVAL, bool ML>
+template <typename K, bool GEN, bool NOVAL>
 __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                   K* __restrict__ kout, uint32_t* __restrict__ vout, SegGeom sg, GenSrc gs, int shift,
                                                   const uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ bintot) {
@@ -250,16 +254,8 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
     }
   }
   __syncthreads();
-  uint64_t* wm = reinterpret_cast<uint64_t*>(skey) + w * 256;        // mask words of this wave (skey is free until the ranking is done)
-  if (ML) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) wm[i * 64 + lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  const uint64_t lanebit = 1ull << lane;
-#pragma unroll
-  for (int s = 0; s < 16; s++) rk[s] = rank_step<ML>((uint32_t)(k[s] >> shift) & 255u, wcnt[w], wm, lanebit);
+  for (int s = 0; s < 16; s++) rk[s] = rank_step((uint32_t)(k[s] >> shift) & 255u, wcnt[w]);
   __syncthreads();
   {
     const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
@@ -742,7 +738,6 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
 // composite (4 passes of 8 bits, wave64 match-any ranking, one LDS staging array) is then a permutation INSIDE every owned
 // group: exactly h slots carry a composite below (h << 20), so the members of the group headed at h land on [h, h + size).
 // The cost does not depend on the group sizes (the counting / bitonic version above degrades with them).
-template <bool ML>
 __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
                                                            uint8_t* __restrict__ dflag) {
   __shared__ uint64_t se[TS_WIN];                // (composite << 32) | suffix: staging of a pass
@@ -820,19 +815,13 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
     if (!owned) pv[s] = 0u;
   }
   if (!__syncthreads_or((int)ownm)) return;      // also: gk (aliasing se) is dead from here
-  const uint64_t lanebit = 1ull << lane;
-  uint64_t* wm = se + w * 256;                   // mask words of this wave: the staging array is dead while a pass ranks
 #pragma unroll 1
   for (int shift = 0; shift < 32; shift += 8) {
     for (int i = tid; i < 1024; i += 256) (&wcnt[0][0])[i] = 0;
-    if (ML) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) wm[i * 64 + lane] = 0;
-    }
     __syncthreads();
     uint32_t rk[16];
 #pragma unroll
-    for (int s = 0; s < 16; s++) rk[s] = rank_step<ML>((comp[s] >> shift) & 255u, wcnt[w], wm, lanebit);
+    for (int s = 0; s < 16; s++) rk[s] = rank_step((comp[s] >> shift) & 255u, wcnt[w]);
     __syncthreads();
     {
       const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
@@ -1112,12 +1101,6 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
   }
 };
 
-// CJS_MATCH=valu: the eight-ballot peer match instead of the LDS mask words (A/B)
-static bool match_lds() {
-  static const bool v = [] { const char* e = getenv("CJS_MATCH"); return !(e && !strcmp(e, "valu")); }();
-  return v;
-}
-
 template <typename K>
 static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
                         LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr, bool noval = false) {
@@ -1143,14 +1126,9 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
       }
     }
     if (lt) lt->begin(s, n);
-#define RS_SCATTER(GEN_, NOVAL_, ML_, G_) hipLaunchKernelGGL((rs_scatter<K, GEN_, NOVAL_, ML_>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, G_, shift, w.hist, T, w.bintot)
-    if (match_lds()) {
-      if (noval) { if (first_gen) RS_SCATTER(true, true, true, *gen); else RS_SCATTER(false, true, true, g0); }
-      else { if (first_gen) RS_SCATTER(true, false, true, *gen); else RS_SCATTER(false, false, true, g0); }
-    } else {
-      if (noval) { if (first_gen) RS_SCATTER(true, true, false, *gen); else RS_SCATTER(false, true, false, g0); }
-      else { if (first_gen) RS_SCATTER(true, false, false, *gen); else RS_SCATTER(false, false, false, g0); }
-    }
+#define RS_SCATTER(GEN_, NOVAL_, G_) hipLaunchKernelGGL((rs_scatter<K, GEN_, NOVAL_>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, G_, shift, w.hist, T, w.bintot)
+    if (noval) { if (first_gen) RS_SCATTER(true, true, *gen); else RS_SCATTER(false, true, g0); }
+    else { if (first_gen) RS_SCATTER(true, false, *gen); else RS_SCATTER(false, false, g0); }
 #undef RS_SCATTER
     if (lt) lt->end(s);
     cur = 1 - cur;
@@ -1172,8 +1150,7 @@ template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uin
 static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag, uint32_t ngroups) {
   static const int forced = !getenv("CJS_TILE_SORT") ? 0 : !strcmp(getenv("CJS_TILE_SORT"), "radix") ? 1 : 2;
   const bool radix = forced ? forced == 1 : (ngroups && A / ngroups >= 5);
-  if (radix && match_lds()) hipLaunchKernelGGL(bwt_tile_sort_radix<true>, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
-  else if (radix) hipLaunchKernelGGL(bwt_tile_sort_radix<false>, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
+  if (radix) hipLaunchKernelGGL(bwt_tile_sort_radix, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
   else hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
 }
 // One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.

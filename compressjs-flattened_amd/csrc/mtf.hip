@@ -193,8 +193,10 @@ __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
   const uint32_t h0 = c * MTF_CHUNK, h1 = h0 + MTF_CHUNK < H ? h0 + MTF_CHUNK : H;
   // 16 heads at a time: one 16-byte load of symbols, one 16-byte store of ranks per lane (hsym/hrank rows
   // are 256-byte aligned: h0 is a multiple of 256 and the per-block stride is padded to 16)
+  uint4 sv_next = *reinterpret_cast<const uint4*>(hsym + h0);
   for (uint32_t hb = h0; hb < h1; hb += 16) {
-    uint4 sv = *reinterpret_cast<const uint4*>(hsym + hb);
+    const uint4 sv = sv_next;
+    if (hb + 16 < h1) sv_next = *reinterpret_cast<const uint4*>(hsym + hb + 16);      // in flight while these 16 heads are replayed
     uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w}, rw[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 16; q++) {
