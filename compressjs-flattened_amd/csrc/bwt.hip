@@ -562,42 +562,116 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t TS_WIN = 4096, TS_MAXGRP = 1024, TS_NOM = TS_WIN - TS_MAXGRP, TS_TINY = 64, TS_GT = 2048;
 
+// Fused rank gather (CJS_FUSE_GATHER, default): the tile sorters of rounds >= 2 make the round's keys themselves -- group
+// ordinal from gord[], rank of suffix val + h out of R -- instead of reading back a key array that bwt_gather_keys wrote: the
+// random rank fetches (bound by the number of 64-byte transactions) then overlap the VALU-bound sorting of the other
+// workgroups of the CU, and 16 B per suffix of key traffic are gone.  Windows overlap, so every slot has ONE window that
+// fetches its rank and writes its key: the window that owns its group, else the window whose nominal range holds it.  The
+// only group a window cannot see whole is the one that runs into it from the left; whether the window before owns that one
+// (<= TS_MAXGRP members, all inside its 4096 slots) follows from the 1024 ordinals in front of the window.
+struct TsGather { const uint32_t* R; const uint32_t* pos; const uint32_t* gord; uint32_t h; int cyclic; Geom g; };
+// slot of step s of a thread: 64 consecutive slots per wave instruction in both layouts (word of a slot = slot >> 6)
+template <bool WMAP> __device__ __forceinline__ uint32_t ts_slot(int s, int tid) {
+  return WMAP ? (uint32_t)(tid >> 6) * 1024u + (uint32_t)s * 64u + (uint32_t)(tid & 63) : (uint32_t)s * 256u + (uint32_t)tid;
+}
+// Loads of the fused form (all issued before the first use): ordinals, suffixes and sorted positions of the window, and the
+// position (+1) of the last ordinal in front of the window that differs from the window's first one (this thread's four).
+template <bool WMAP>
+__device__ __forceinline__ uint32_t ts_fused_load(const TsGather& tg, const uint32_t* __restrict__ val, uint64_t wb, uint32_t L,
+                                                  uint32_t (&go)[16], uint32_t (&pv)[16], uint32_t (&pp)[16], uint32_t& gprev) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < 16; s++) { const uint32_t x = ts_slot<WMAP>(s, tid); go[s] = tg.gord[wb + (x < L ? x : L - 1u)]; }
+#pragma unroll
+  for (int s = 0; s < 16; s++) { const uint32_t x = ts_slot<WMAP>(s, tid); pv[s] = val[wb + (x < L ? x : L - 1u)]; }
+#pragma unroll
+  for (int s = 0; s < 16; s++) { const uint32_t x = ts_slot<WMAP>(s, tid); pp[s] = tg.pos[wb + (x < L ? x : L - 1u)]; }
+  uint32_t li = 0;
+  gprev = 0xFFFFFFFFu;
+  if (wb) {                                       // wb is a multiple of TS_NOM >= TS_MAXGRP
+    const uint32_t* q = tg.gord + wb - TS_MAXGRP + (uint32_t)tid * 4u;
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], g0 = tg.gord[wb];
+    gprev = tg.gord[wb - 1];
+    li = q3 != g0 ? (uint32_t)tid * 4u + 4u : q2 != g0 ? (uint32_t)tid * 4u + 3u : q1 != g0 ? (uint32_t)tid * 4u + 2u : q0 != g0 ? (uint32_t)tid * 4u + 1u : 0u;
+  }
+#pragma unroll
+  for (int s = 0; s < 16; s++) if (ts_slot<WMAP>(s, tid) >= L) go[s] = 0xFFFFFFFFu;
+  return li;
+}
+// slots [0, result) of the window belong to a group that the window before owns (hm / wnext of this window are known)
+__device__ __forceinline__ uint32_t ts_prev_end(uint64_t wb, uint32_t L, bool at_end, uint32_t li_max, const uint64_t* hm, const int32_t* wnext) {
+  const uint64_t m0 = hm[0];
+  if (!wb || (m0 & 1ull)) return 0u;              // the first slot starts a group
+  const uint32_t sb = TS_MAXGRP - li_max;         // members in front of the window (TS_MAXGRP: or more)
+  const uint32_t fh = m0 ? (uint32_t)__builtin_ctzll(m0) : (uint32_t)wnext[0];
+  const uint32_t e = fh <= L ? fh : (at_end ? L : TS_WIN + 1u);
+  return sb + e <= TS_MAXGRP ? e : 0u;
+}
+// rank keys of the slots in `need` (bit s = step s): R[suffix + h] + 1 of the suffix's block, 0 past the end (sentinel form)
+__device__ __forceinline__ void ts_fused_gather(const TsGather& tg, uint32_t need, const uint32_t (&pv)[16], uint32_t (&pp)[16], uint32_t (&rk20)[16]) {
+  uint32_t past = 0;
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t blk = pp[s] / tg.g.stride, n = blk_len(tg.g, blk);
+    uint32_t j = pv[s] + tg.h;
+    if (tg.cyclic) { if (j >= n) j %= n; }
+    else if (j >= n) { j = 0; past |= 1u << s; }
+    pp[s] = blk * tg.g.stride + j;               // (positions are 32 bits wide: bwt_run refuses more)
+  }
+#pragma unroll
+  for (int s = 0; s < 16; s++) rk20[s] = tg.R[((need >> s) & 1u) ? pp[s] : pp[0]];
+#pragma unroll
+  for (int s = 0; s < 16; s++) rk20[s] = ((past >> s) & 1u) ? 0u : rk20[s] + 1u;
+}
+
 __device__ __forceinline__ void ts_ce(uint64_t& a, uint64_t& b, bool up) {
   const bool sw = (a > b) == up;
   const uint64_t x = sw ? b : a, y = sw ? a : b;
   a = x; b = y;
 }
+template <bool FUSED>
 __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
-                                                     uint8_t* __restrict__ dflag) {
+                                                     uint8_t* __restrict__ dflag, TsGather tg, uint32_t Tt) {
   __shared__ uint64_t sk[TS_WIN];
   __shared__ uint64_t hm[64];                    // head mask of the window
   __shared__ int32_t wlast[64], wnext[64];       // last head before word / first head after word (window slot, -1 / TS_WIN+1 = none)
   uint32_t* gk = (uint32_t*)sk;                  // group ordinals of the window slots (only until the heads are known)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const uint64_t wb = (uint64_t)blockIdx.x * TS_NOM;
+  __shared__ uint32_t lired[4];
+  const uint32_t win = xcd_tile(blockIdx.x, Tt);            // windows of one block on one XCD: its ranks stay in that L2
+  if (win >= Tt) return;
+  const uint64_t wb = (uint64_t)win * TS_NOM;
   const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
   const uint32_t L = (uint32_t)(we - wb);
   uint64_t r[16];
-  uint32_t pv[16];
+  uint32_t pv[16], go[16], pp[FUSED ? 16 : 1];          // go: group ordinal of slot it*256+tid
+  uint32_t gprev;
   // every global load of the window (keys and suffixes) is issued before the first LDS store: written as one loop the
   // compiler waits for each load in turn, sixteen memory round trips instead of one
+  if constexpr (FUSED) {
+    const uint32_t li = wave_max(ts_fused_load<false>(tg, val, wb, L, go, pv, pp, gprev));
+    if (lane == 0) lired[w] = li;
+  } else {
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const uint32_t x = (uint32_t)it * 256u + tid;
-    r[it] = key[wb + (x < L ? x : L - 1u)];
+    for (int it = 0; it < 16; it++) {
+      const uint32_t x = (uint32_t)it * 256u + tid;
+      r[it] = key[wb + (x < L ? x : L - 1u)];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint32_t x = (uint32_t)it * 256u + tid;
+      pv[it] = val[wb + (x < L ? x : L - 1u)];
+    }
+    gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint32_t x = (uint32_t)it * 256u + tid;
+      if (x >= L) r[it] = ~0ull;
+      go[it] = (uint32_t)(r[it] >> 20);
+    }
   }
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const uint32_t x = (uint32_t)it * 256u + tid;
-    pv[it] = val[wb + (x < L ? x : L - 1u)];
-  }
-  const uint32_t gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
-#pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const uint32_t x = (uint32_t)it * 256u + tid;
-    if (x >= L) r[it] = ~0ull;
-    gk[x] = (uint32_t)(r[it] >> 20);
-  }
+  for (int it = 0; it < 16; it++) gk[(uint32_t)it * 256u + tid] = go[it];
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < 16; it++) {
@@ -626,7 +700,11 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
   __shared__ uint32_t mpre[65];
   int any_medium = 0;
   uint32_t hx16[16];          // head slot (low 16 bits) | group size (high 16 bits) of owned slots, 0xFFFFFFFF otherwise
-  uint32_t go[16];            // group ordinal of slot it*256+tid
+  uint32_t prev_end = 0, needm = 0;
+  if constexpr (FUSED) {
+    const uint32_t a01 = lired[0] > lired[1] ? lired[0] : lired[1], a23 = lired[2] > lired[3] ? lired[2] : lired[3];
+    prev_end = ts_prev_end(wb, L, we == A, a01 > a23 ? a01 : a23, hm, wnext);
+  }
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t x = (uint32_t)it * 256u + tid;
@@ -646,11 +724,25 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     const uint64_t mb = __ballot(medium);
     if (lane == 0) mm[wi] = mb;
     any_medium |= medium ? 1 : 0;
-    const uint64_t k = r[it];
-    go[it] = (uint32_t)(k >> 20);
-    const uint64_t v = owned ? (uint64_t)pv[it] : 0ull;
-    r[it] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
-                  : (((uint64_t)x << 52) | (0xFFFFFull << 32));
+    if constexpr (FUSED) needm |= (valid && x >= prev_end && (owned || x < TS_NOM)) ? 1u << it : 0u;
+    else {
+      const uint64_t k = r[it];
+      const uint64_t v = owned ? (uint64_t)pv[it] : 0ull;
+      r[it] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
+                    : (((uint64_t)x << 52) | (0xFFFFFull << 32));
+    }
+  }
+  if constexpr (FUSED) {
+    uint32_t rk20[16];
+    ts_fused_gather(tg, needm, pv, pp, rk20);
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint32_t x = (uint32_t)it * 256u + tid;
+      const bool owned = hx16[it] != 0xFFFFFFFFu;
+      if (((needm >> it) & 1u) && !owned) key[wb + x] = ((uint64_t)go[it] << 20) | rk20[it];      // not sorted here: the key as gathered
+      r[it] = owned ? (((uint64_t)(hx16[it] & 0xFFFFu) << 52) | ((uint64_t)rk20[it] << 32) | pv[it])
+                    : (((uint64_t)x << 52) | (0xFFFFFull << 32));
+    }
   }
   __syncthreads();            // gk (aliasing sk) is dead from here
   // groups of <= TS_TINY members: every member counts the smaller members of its group.  Inside a group only the
@@ -738,8 +830,9 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
 // composite (4 passes of 8 bits, wave64 match-any ranking, one LDS staging array) is then a permutation INSIDE every owned
 // group: exactly h slots carry a composite below (h << 20), so the members of the group headed at h land on [h, h + size).
 // The cost does not depend on the group sizes (the counting / bitonic version above degrades with them).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
-                                                           uint8_t* __restrict__ dflag) {
+                                                           uint8_t* __restrict__ dflag, TsGather tg, uint32_t Tt) {
   __shared__ uint64_t se[TS_WIN];                // (composite << 32) | suffix: staging of a pass
   __shared__ uint64_t hm[64];
   __shared__ int32_t wlast[64], wnext[64];
@@ -747,12 +840,21 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
   __shared__ uint32_t sm[4];
   uint32_t* gk = (uint32_t*)se;                  // group ordinals of the window slots (only until the heads are known)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const uint64_t wb = (uint64_t)blockIdx.x * TS_NOM;
+  __shared__ uint32_t lired[4];
+  const uint32_t win = xcd_tile(blockIdx.x, Tt);            // windows of one block on one XCD: its ranks stay in that L2
+  if (win >= Tt) return;
+  const uint64_t wb = (uint64_t)win * TS_NOM;
   const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
   const uint32_t L = (uint32_t)(we - wb);
   // slot of (wave w, step s, lane): w * 1024 + s * 64 + lane -- array order = (w, s, lane) order, which the stable ranking needs
-  uint32_t rk20[16], go[16], pv[16];
-  {
+  uint32_t rk20[16], go[16], pv[16], pp[FUSED ? 16 : 1];
+  uint32_t gprev;
+  if constexpr (FUSED) {
+    const uint32_t li = wave_max(ts_fused_load<true>(tg, val, wb, L, go, pv, pp, gprev));
+    if (lane == 0) lired[w] = li;
+#pragma unroll
+    for (int s = 0; s < 16; s++) gk[ts_slot<true>(s, tid)] = go[s];
+  } else {
     uint64_t k[16];                              // every load is issued before the first LDS store
 #pragma unroll
     for (int s = 0; s < 16; s++) {
@@ -771,8 +873,8 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
       go[s] = (uint32_t)(k[s] >> 20); rk20[s] = (uint32_t)k[s] & 0xFFFFFu;
       gk[x] = go[s];
     }
+    gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
   }
-  const uint32_t gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 16; s++) {
@@ -796,8 +898,13 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
     wlast[lane] = el; wnext[lane] = en;
   }
   __syncthreads();
+  uint32_t prev_end = 0;
+  if constexpr (FUSED) {
+    const uint32_t a01 = lired[0] > lired[1] ? lired[0] : lired[1], a23 = lired[2] > lired[3] ? lired[2] : lired[3];
+    prev_end = ts_prev_end(wb, L, we == A, a01 > a23 ? a01 : a23, hm, wnext);
+  }
   uint32_t comp[16];
-  uint32_t ownm = 0;
+  uint32_t ownm = 0, needm = 0;
 #pragma unroll
   for (int s = 0; s < 16; s++) {
     const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
@@ -811,9 +918,21 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
     const bool owned = x < L && hx >= 0 && nx <= (int)L && (uint32_t)(nx - hx) <= TS_MAXGRP && (uint32_t)hx < TS_NOM;
     if (owned && dflag) dflag[wb + x] = 0;
     ownm |= owned ? 1u << s : 0u;
-    comp[s] = owned ? (((uint32_t)hx << 20) | rk20[s]) : (x << 20);
-    if (!owned) pv[s] = 0u;
+    if constexpr (FUSED) { needm |= (x < L && x >= prev_end && (owned || x < TS_NOM)) ? 1u << s : 0u; comp[s] = (uint32_t)hx; }
+    else comp[s] = owned ? (((uint32_t)hx << 20) | rk20[s]) : (x << 20);
   }
+  if constexpr (FUSED) {
+    ts_fused_gather(tg, needm, pv, pp, rk20);
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
+      const bool owned = (ownm >> s) & 1u;
+      if (((needm >> s) & 1u) && !owned) key[wb + x] = ((uint64_t)go[s] << 20) | rk20[s];      // not sorted here: the key as gathered
+      comp[s] = owned ? ((comp[s] << 20) | rk20[s]) : (x << 20);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 16; s++) if (!((ownm >> s) & 1u)) pv[s] = 0u;
   if (!__syncthreads_or((int)ownm)) return;      // also: gk (aliasing se) is dead from here
 #pragma unroll 1
   for (int shift = 0; shift < 32; shift += 8) {
@@ -1058,7 +1177,7 @@ size_t BwtWork::bytes_needed(size_t cap) {
   size_t b = 0;
   auto add = [&](size_t n) { b += (n + 255) & ~(size_t)255; };
   add(cap * 8); add(cap * 8); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4);  // key x2, val x2, pos x2, gord
-  add(cap * 4); add(cap * 4);           // R, SA
+  add(cap * 4); add(cap * 4); add(cap);           // R, SA, dflag
   add(hist_words(T) * 4); add(256 * segs_for(cap) * 4); add(3 * T * 4); add(64); add(16 * 256 * 4);
   return b + 4096;
 }
@@ -1070,7 +1189,7 @@ int BwtWork::carve(Arena& a, size_t cap_) {
   val[0] = a.take<uint32_t>(cap); val[1] = a.take<uint32_t>(cap);
   pos[0] = a.take<uint32_t>(cap); pos[1] = a.take<uint32_t>(cap);
   gord = a.take<uint32_t>(cap);
-  R = a.take<uint32_t>(cap); SA = a.take<uint32_t>(cap);
+  R = a.take<uint32_t>(cap); SA = a.take<uint32_t>(cap); dflag = a.take<uint8_t>(cap);
   hist = a.take<uint32_t>(hist_words(T)); bintot = a.take<uint32_t>(256 * (size_t)bintot_segs);
   tile_cnt = a.take<uint32_t>(3 * T); counters = a.take<uint32_t>(16);
   ghist = a.take<uint32_t>(16 * 256);
@@ -1147,27 +1266,37 @@ template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uin
 // Which tile sorter: the LDS radix version costs the same whatever the groups look like (18 ps per suffix), the counting /
 // bitonic version is cheaper once the groups are tiny (round 2 of the bench text, 7.7 suffixes per group: 1.51 vs 1.82 ms;
 // round 3, 3.5 per group: 0.67 vs 0.64 ms; later rounds up to 2x in favour of counting).  CJS_TILE_SORT=radix|count forces one.
-static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag, uint32_t ngroups) {
+static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag, uint32_t ngroups, const TsGather* tg) {
   static const int forced = !getenv("CJS_TILE_SORT") ? 0 : !strcmp(getenv("CJS_TILE_SORT"), "radix") ? 1 : 2;
   const bool radix = forced ? forced == 1 : (ngroups && A / ngroups >= 5);
-  if (radix) hipLaunchKernelGGL(bwt_tile_sort_radix, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
-  else hipLaunchKernelGGL(bwt_tile_sort, dim3(Tt), dim3(256), 0, s, key, val, A, dflag);
+  const TsGather t0{nullptr, nullptr, nullptr, 0u, 0, Geom{0u, 0u, 0u}};
+  if (radix) {
+    if (tg) hipLaunchKernelGGL(bwt_tile_sort_radix<true>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, *tg, Tt);
+    else hipLaunchKernelGGL(bwt_tile_sort_radix<false>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, t0, Tt);
+  } else {
+    if (tg) hipLaunchKernelGGL(bwt_tile_sort<true>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, *tg, Tt);
+    else hipLaunchKernelGGL(bwt_tile_sort<false>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, t0, Tt);
+  }
+}
+// the tile sorters take the round (else: whole-array radix passes on keys that bwt_gather_keys has to write first)
+static bool tile_sorted_round(uint32_t A) {
+  static const bool no_tiles = getenv("CJS_NO_TILE_SORT") != nullptr;
+  return !no_tiles && A >= 2 * TS_WIN;
 }
 // One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.
 // Works in place on (key[c], val[c]); only the whole-array fallback flips c.
-static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt, uint32_t ngroups) {
-  static const bool no_tiles = getenv("CJS_NO_TILE_SORT") != nullptr;
-  if (no_tiles || A < 2 * TS_WIN) return radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, lt);
+static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt, uint32_t ngroups, const TsGather* tg) {
+  if (!tile_sorted_round(A)) return radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, lt);
   const uint32_t Tt = (A + TS_NOM - 1) / TS_NOM, Tg = (A + TS_GT - 1) / TS_GT;
-  uint8_t* dflag = (uint8_t*)w.gord;                    // gord is dead between bwt_gather_keys and bwt_apply
+  uint8_t* dflag = w.dflag;
   uint32_t* tcount = w.tile_cnt;                        // 3*cap/4096 entries >= cap/2048
   if (w.no_large_groups) {                              // groups only ever split: once none exceeds TS_MAXGRP, none will
-    launch_tile_sort(s, Tt, w.key[c], w.val[c], A, nullptr, ngroups);
+    launch_tile_sort(s, Tt, w.key[c], w.val[c], A, nullptr, ngroups, tg);
     CJS_HIP_TRY(hipGetLastError());
     return 0;
   }
   CJS_HIP_TRY(hipMemsetAsync(dflag, 1, A, s));
-  launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag, ngroups);
+  launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag, ngroups, tg);
   hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, tcount);
   hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2, w.h_counters + 2);      // the kernel writes the pinned mirror itself
   CJS_HIP_TRY(hipStreamSynchronize(s));
@@ -1231,6 +1360,9 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   // two-sweep scheduling of the round-1 rank scatter (see HalfMap): pays only with the packed records (the second sweep of the
   // 12-byte key + value form re-reads more than the merged stores save: 2.15 vs 1.64 ms)
   const bool sweeps = env_halves >= 2 && nb >= 8 && packed;
+  static const bool env_fuse = getenv("CJS_FUSE_GATHER") == nullptr || atoi(getenv("CJS_FUSE_GATHER")) != 0;
+  bool fuse = false;
+  TsGather tg{nullptr, nullptr, nullptr, 0u, 0, g};
   for (;;) {
     if (rounds == 0) {
       if (packed) {
@@ -1245,7 +1377,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
         }
       } else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
-    } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups));
+    } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups, fuse ? &tg : nullptr));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
@@ -1274,7 +1406,9 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
       break;
     }
     if (rounds > 40) return CJS_E_HIP;    // cannot happen: depth doubles every round
-    {
+    fuse = env_fuse && tile_sorted_round(A);       // the tile sorters fetch the ranks themselves
+    if (fuse) tg = TsGather{w.R, w.pos[pc], w.gord, h, (int)cyclic, g};
+    else {
       const uint32_t Tg = (A + RS_TILE - 1) / RS_TILE;
       hipLaunchKernelGGL(bwt_gather_keys, dim3(xcd_grid(Tg)), dim3(256), 0, s, g, (int)cyclic, A, h, w.R, w.val[c], w.pos[pc], w.gord, w.key[c], Tg);
     }

@@ -92,6 +92,7 @@ struct BwtWork {
   uint32_t* gord = nullptr;
   uint32_t* R = nullptr;
   uint32_t* SA = nullptr;
+  uint8_t* dflag = nullptr;      // per slot of a round >= 2: 1 = its group is too large for the tile sorters
   uint32_t* hist = nullptr;      // hist_words(tiles): 256 per tile (tile-major) + the chunk sums of the long-segment scan
   uint32_t* bintot = nullptr;    // 256 per segment
   uint32_t* tile_cnt = nullptr;  // 3 * tiles (+ scanned copies)
