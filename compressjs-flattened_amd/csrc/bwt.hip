@@ -1020,46 +1020,86 @@ __global__ __launch_bounds__(256) void bwt_flush_active(uint32_t A, const uint32
 // bytes 2..6; here every sorted slot learns r1 = block-local slot of the head of its (bytes 2..6) class and becomes the
 // phase-2 record  byte0 . byte1 (bits 63..48) | r1 (47..28) | parity (20) | position (19..0); two more stable passes on the
 // top 16 bits then order by (byte0, byte1, class of bytes 2..6), and key >> 20 is the 7-byte group key.
-// Same head bookkeeping as bwt_apply: head masks by ballot, carry of the last head in front of the tile from bwt_scan_tiles.
-__global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __restrict__ key, uint32_t A, Geom g, const uint8_t* __restrict__ T,
-                                                          const uint32_t* __restrict__ tile_cnt, uint32_t Tn, uint64_t* __restrict__ out) {
+// Tiles are the tiles of the segmented radix passes (one segment per block), so this kernel also leaves the per-tile
+// histogram of byte1 -- the digit of the first phase-2 pass -- in hist[], and that pass needs no rs_hist of its own.
+// No flag / scan passes in front either: the only class head a tile cannot see is the one of the class that runs into it,
+// and the block is sorted, so wave 0 finds it by looking at the 64 slots in front of the tile (nearly always enough) and
+// otherwise by a 64-way search for the lower bound of the tile's first key in the block.
+__global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __restrict__ key, SegGeom sg, const uint8_t* __restrict__ T,
+                                                          uint32_t* __restrict__ hist, uint64_t* __restrict__ out) {
   __shared__ uint64_t sk[RS_TILE + 1];
   __shared__ uint64_t m_nh[64];
   __shared__ uint32_t wp_head[64];
+  constexpr int PH = 2;                          // histogram copies per wave (the 32 KB of sk[] limit the residency already)
+  __shared__ uint32_t h[4 * 256 * PH];
+  __shared__ uint32_t carry_s;
   const uint32_t tile = blockIdx.x;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const uint64_t base = (uint64_t)tile * RS_TILE;
-  const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
+  const TileRef t = tile_ref(sg, tile);
+  if (!t.nvalid) { hist[(size_t)tile * 256 + tid] = 0; return; }
+  const uint64_t base = t.base, seg0 = (uint64_t)t.seg * sg.stride;
+  const uint32_t nvalid = t.nvalid, n = t.seg + 1 == sg.nseg ? sg.n_last : sg.stride;
   uint64_t k16[16];                              // all loads first (see bwt_apply)
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
     k16[it] = __builtin_nontemporal_load(key + base + (e < nvalid ? e : nvalid - 1u));
   }
-  if (tid == 0) sk[0] = base ? key[base - 1] : ~0ull;
+  if (tid == 64) sk[0] = t.off ? key[base - 1] : ~0ull;
+  if (w == 0) {
+    // head of the class of the tile's first slot (global index + 1, as bwt_scan_tiles would have carried it)
+    uint32_t carry = (uint32_t)base + 1u;
+    if (t.off) {
+      const uint64_t target = key[base] >> PK_SHIFT;
+      const uint32_t back = t.off < 64u ? t.off : 64u;                  // slots in front of the tile, inside the block
+      const bool eq = (uint32_t)lane < back && (key[base - 1u - (uint32_t)lane] >> PK_SHIFT) == target;
+      const uint64_t ne = ~__ballot(eq);
+      const uint32_t m = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;      // slots base-1 .. base-m carry the class
+      uint64_t head = base - m;
+      if (m == 64u && t.off > 64u) {                                    // the class is longer: lower bound of target in [seg0, base - 64]
+        uint64_t lo = seg0, hi = base - 64u;                            // key[hi] is known to carry the class
+        while (hi > lo) {
+          const uint64_t len = hi - lo, step = (len + 63u) / 64u, idx = lo + (uint64_t)lane * step;
+          const bool hit = idx >= hi || (key[idx] >> PK_SHIFT) == target;
+          const uint64_t hits = __ballot(hit);
+          const uint32_t j = hits ? (uint32_t)__builtin_ctzll(hits) : 64u;   // first probe inside the class (64: none, it starts behind the last probe)
+          if (!j) { hi = lo; break; }
+          const uint64_t nhi = lo + (uint64_t)j * step;
+          lo += (uint64_t)(j - 1u) * step + 1u;
+          if (j < 64u && nhi < hi) hi = nhi;
+        }
+        head = hi;
+      }
+      carry = (uint32_t)head + 1u;
+    }
+    if (lane == 0) carry_s = carry;
+  }
   // the two leading bytes of every record's suffix: gathers from the block text (L2), independent of everything below
   uint32_t b01[16];
+  {
+    const uint8_t* tx = T + seg0;
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const uint32_t e = (uint32_t)it * 256u + tid;
-    const uint32_t a = (uint32_t)base + (e < nvalid ? e : nvalid - 1u);
-    const uint32_t blk = a / g.stride, n = blk_len(g, blk);
-    const uint32_t p = (uint32_t)k16[it] & PK_POS_MASK;
-    const uint8_t* t = T + (size_t)blk * g.stride;
-    b01[it] = ((uint32_t)t[p] << 8) | t[p + 1 < n ? p + 1 : 0];
+    for (int it = 0; it < 16; it++) {
+      const uint32_t p = (uint32_t)k16[it] & PK_POS_MASK;
+      b01[it] = ((uint32_t)tx[p] << 8) | tx[p + 1 < n ? p + 1 : 0];
+    }
   }
+#pragma unroll
+  for (int i = 0; i < 4 * PH; i++) h[i * 256 + tid] = 0;
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
     sk[e + 1] = e < nvalid ? k16[it] : ~0ull;
   }
   __syncthreads();
-#pragma unroll 4
+  uint32_t* hw = h + w * 256 * PH + (tid & (PH - 1));      // (bank-interleaved copies as in rs_hist)
+#pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
-    const bool nh = e < nvalid && (base + e == 0 || (sk[e] >> PK_SHIFT) != (sk[e + 1] >> PK_SHIFT));
+    const bool nh = e < nvalid && (t.off + e == 0 || (sk[e] >> PK_SHIFT) != (sk[e + 1] >> PK_SHIFT));
     const uint64_t mnh = __ballot(nh);
     if (lane == 0) m_nh[it * 4 + w] = mnh;
+    if (e < nvalid) atomicAdd(&hw[(b01[it] & 255u) * PH], 1u);
   }
   __syncthreads();
   if (w == 0) {
@@ -1070,8 +1110,16 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
     if (lane == 0) em = 0;
     wp_head[lane] = em;
   }
+  {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int r = 0; r < PH; r++) sum += h[i * 256 * PH + tid * PH + r];
+    hist[(size_t)tile * 256 + tid] = sum;
+  }
   __syncthreads();
-  const uint32_t carry = tile_cnt[2 * (size_t)Tn + tile];
+  const uint32_t carry = carry_s;
   const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
 #pragma unroll
   for (int it = 0; it < 16; it++) {
@@ -1080,11 +1128,9 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
       const int wi = it * 4 + w;
       const uint64_t hm = m_nh[wi] & le;
       const uint32_t head_a = hm ? (uint32_t)base + (uint32_t)wi * 64u + 63u - (uint32_t)__builtin_clzll(hm) : wp_head[wi] ? (uint32_t)base + wp_head[wi] - 1u : carry - 1u;
-      const uint32_t a = (uint32_t)base + e;
-      const uint32_t blk = a / g.stride;
       const uint64_t k = k16[it];
-      const uint32_t r1 = head_a - blk * g.stride;
-      __builtin_nontemporal_store(((uint64_t)b01[it] << 48) | ((uint64_t)r1 << 28) | (k & ((1ull << (PK_SHIFT + 1)) - 1ull)), out + a);
+      const uint32_t r1 = head_a - (uint32_t)seg0;
+      __builtin_nontemporal_store(((uint64_t)b01[it] << 48) | ((uint64_t)r1 << 28) | (k & ((1ull << (PK_SHIFT + 1)) - 1ull)), out + base + e);
     }
   }
 }
@@ -1222,7 +1268,8 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
 
 template <typename K>
 static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
-                        LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr, bool noval = false) {
+                        LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr, bool noval = false,
+                        bool first_hist_ready = false) {       // first_hist_ready: w.hist already holds the tile counts of the first digit
   const uint32_t T1 = (n + RS_TILE - 1) / RS_TILE;
   const SegGeom sg = seg ? *seg : SegGeom{1u, n, n, T1};
   const uint32_t T = sg.nseg * sg.tps;
@@ -1231,7 +1278,8 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
   const GenSrc g0{nullptr, 0, 0, 0};
   for (int shift = lo_bit; shift < hi_bit; shift += 8) {
     const bool first_gen = gen && shift == lo_bit;        // the first pass makes its keys from the block bytes
-    if (first_gen) hipLaunchKernelGGL((rs_hist<K, true>), dim3(T), dim3(256), 0, s, kk[cur], sg, *gen, shift, w.hist, T);
+    if (first_hist_ready && shift == lo_bit) {}
+    else if (first_gen) hipLaunchKernelGGL((rs_hist<K, true>), dim3(T), dim3(256), 0, s, kk[cur], sg, *gen, shift, w.hist, T);
     else hipLaunchKernelGGL((rs_hist<K, false>), dim3(T), dim3(256), 0, s, kk[cur], sg, g0, shift, w.hist, T);
     if (sg.tps <= 4 * SB_CHUNK) hipLaunchKernelGGL(rs_scan_bins, dim3(sg.nseg), dim3(256), 0, s, w.hist, sg.tps, w.bintot);
     else {                                    // one long segment (nseg > 1 with long segments: still correct, one launch per segment)
@@ -1368,12 +1416,9 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
       if (packed) {
         CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
         if (two_phase) {
-        const uint32_t T1 = (A + RS_TILE - 1) / RS_TILE;
-        hipLaunchKernelGGL(bwt_flags, dim3(T1), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T1, PK_SHIFT);
-        hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T1, w.counters, w.h_counters);
-        hipLaunchKernelGGL(bwt_phase2_records, dim3(T1), dim3(256), 0, s, w.key[c], A, g, d_T, w.tile_cnt, T1, w.key[1 - c]);
+          hipLaunchKernelGGL(bwt_phase2_records, dim3(sg.nseg * sg.tps), dim3(256), 0, s, w.key[c], sg, d_T, w.hist, w.key[1 - c]);
           c = 1 - c;
-          CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true)));
+          CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true, true)));
         }
       } else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
