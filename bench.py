@@ -212,18 +212,23 @@ def main():
     t0 = time.perf_counter()
     res = None
     for _ in range(args.steps):
+        # inside the timed loop the library only records events (whole call + every launch of the dominant kernel): the
+        # per-stage times need a stream synchronisation per stage and come from one extra, untimed step below
         st = pkg.Stats()
+        st.flags = pkg.Stats.NO_STAGE_TIMES
         res = step(st)
         agg["dom_ms"] += st.ms_bwt_dominant * st.bwt_dominant_launches
         agg["dom_launches"] += st.bwt_dominant_launches
         agg["dom_elems"] += st.bwt_dominant_bytes
-        for k in ("ms_total", "ms_rle1", "ms_bwt", "ms_mtf", "ms_huff", "ms_pack"):
-            agg["stage"][k] = agg["stage"].get(k, 0.0) + getattr(st, k)
         agg["step_ms"].append(st.ms_total)
         last_stats = st
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    st = pkg.Stats()
+    step(st)                                             # untimed: stage breakdown (synchronises between the stages)
+    for k in ("ms_total", "ms_rle1", "ms_bwt", "ms_mtf", "ms_huff", "ms_pack"):
+        agg["stage"][k] = getattr(st, k) * args.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,7 +353,7 @@ def main():
                          "algorithmic_bytes_per_input_byte": round(ratio, 4),
                          "pipeline_achieved_GBs": round(ratio * total_in / elapsed / 1e9, 3)},
             "cpu_baseline": cpu_baseline,
-            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in agg["stage"].items()},
+            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in agg["stage"].items()},      # one extra untimed step with per-stage synchronisation
             "bwt_rounds": int(last_stats.bwt_rounds),
             "verify": verify,
         }

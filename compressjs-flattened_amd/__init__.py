@@ -28,7 +28,8 @@ class Stats(ctypes.Structure):
                 ("ms_mtf", ctypes.c_double), ("ms_huff", ctypes.c_double), ("ms_pack", ctypes.c_double),
                 ("ms_bwt_dominant", ctypes.c_double), ("bwt_dominant_launches", ctypes.c_uint64),
                 ("bwt_dominant_bytes", ctypes.c_uint64), ("blocks", ctypes.c_uint64), ("bytes_in", ctypes.c_uint64),
-                ("bytes_out", ctypes.c_uint64), ("bwt_rounds", ctypes.c_uint32)]
+                ("bytes_out", ctypes.c_uint64), ("bwt_rounds", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+    NO_STAGE_TIMES = 1          # CJS_STATS_NO_STAGE_TIMES: no stream synchronisation between the stages
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   const uint64_t base = (uint64_t)tile * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
   // every streaming load of the tile is issued up front (one loop of load + LDS store makes the compiler wait per load)
+  const uint32_t sbase = tile_cnt[tile], hbase = tile_cnt[T + tile], carry = tile_cnt[2 * (size_t)T + tile];
   uint32_t p16[FIRST ? 1 : 16], v16[PACKED ? 1 : 16];
   {
     uint64_t k16[16];
@@ -514,7 +515,6 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
     wp_s[lane] = is - sv; wp_h[lane] = ih - hd; wp_head[lane] = em;
   }
   __syncthreads();
-  const uint32_t sbase = tile_cnt[tile], hbase = tile_cnt[T + tile], carry = tile_cnt[2 * (size_t)T + tile];
   const uint64_t lt = (1ull << lane) - 1ull, le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
 #pragma unroll
   for (int it = 0; it < 16; it++) {
@@ -1244,28 +1244,6 @@ int BwtWork::carve(Arena& a, size_t cap_) {
   return 0;
 }
 
-struct LaunchTimes {   // event pairs around the dominant kernel; resolved after the stream has drained
-  static constexpr int MAXP = 512;
-  hipEvent_t ev[2 * MAXP];
-  uint64_t elems[MAXP];
-  int n = 0, made = 0;
-  bool enabled = false;
-  void begin(hipStream_t s, uint64_t e) {
-    if (!enabled || n >= MAXP) return;
-    while (made < 2 * (n + 1)) { if (hipEventCreate(&ev[made]) != hipSuccess) { enabled = false; return; } made++; }
-    elems[n] = e;
-    (void)hipEventRecord(ev[2 * n], s);
-  }
-  void end(hipStream_t s) { if (!enabled || n >= MAXP) return; (void)hipEventRecord(ev[2 * n + 1], s); n++; }
-  void resolve(cjs_stats* st) {
-    double ms = 0; uint64_t e = 0;
-    for (int i = 0; i < n; i++) { float t = 0; if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { ms += t; e += elems[i]; } }
-    if (st && n) { st->ms_bwt_dominant = ms / n; st->bwt_dominant_launches = (uint64_t)n; st->bwt_dominant_bytes = e; }
-    for (int i = 0; i < made; i++) (void)hipEventDestroy(ev[i]);
-    n = made = 0;
-  }
-};
-
 template <typename K>
 static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
                         LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr, bool noval = false,
@@ -1366,7 +1344,7 @@ static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int
 }
 
 int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t stride, uint32_t n_last,
-            bool cyclic, uint8_t* d_U, uint32_t* d_pidx, cjs_stats* stats) {
+            bool cyclic, uint8_t* d_U, uint32_t* d_pidx, cjs_stats* stats, bool resolve_stats) {
   if (nb == 0) return 0;
   const uint64_t M64 = (uint64_t)(nb - 1) * stride + n_last;
   if (M64 > w.cap || M64 >= 0xFFFFF000ull) return CJS_E_INVALID_ARG;
@@ -1375,7 +1353,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   const Geom g{nb, stride, n_last};
   const uint32_t max_n = nb > 1 ? stride : n_last;
   const int grid_lin = (int)((M + 255) / 256 < 65535u * 16u ? (M + 255) / 256 : 65535u * 16u);
-  LaunchTimes lt; lt.enabled = stats != nullptr;
+  LaunchTimes& lt = w.lt; lt.reset(); lt.enabled = stats != nullptr;
 
   int c = 0, pc = 0;        // current key/val buffer, current pos buffer
   CJS_HIP_TRY(hipMemsetAsync(w.counters, 0, 64, s));
@@ -1466,10 +1444,10 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     hipLaunchKernelGGL(bwt_emit, dim3(xcd_grid(Tn)), dim3(256), 0, s, d_T, g, (int)cyclic, M, w.SA, w.R, d_U, Tn);
   }
   CJS_HIP_TRY(hipGetLastError());
-  if (stats) {
+  if (stats) stats->bwt_rounds = rounds;
+  if (stats && resolve_stats) {                  // (else the caller resolves w.lt once its stream has drained)
     CJS_HIP_TRY(hipStreamSynchronize(s));
     lt.resolve(stats);
-    stats->bwt_rounds = rounds;
   }
   return 0;
 }

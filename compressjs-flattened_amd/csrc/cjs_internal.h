@@ -84,6 +84,28 @@ inline void Arena::destroy() {
 constexpr uint32_t RS_TILE = 4096;   // radix-sort tile (256 threads x 16 keys)
 
 // Workspace of the suffix sorter for up to `cap` suffixes (all blocks of a batch together).
+struct LaunchTimes {   // event pairs around the dominant kernel; resolved after the stream has drained
+  static constexpr int MAXP = 512;
+  hipEvent_t ev[2 * MAXP];
+  uint64_t elems[MAXP];
+  int n = 0, made = 0;
+  bool enabled = false;
+  void begin(hipStream_t s, uint64_t e) {
+    if (!enabled || n >= MAXP) return;
+    while (made < 2 * (n + 1)) { if (hipEventCreate(&ev[made]) != hipSuccess) { enabled = false; return; } made++; }
+    elems[n] = e;
+    (void)hipEventRecord(ev[2 * n], s);
+  }
+  void end(hipStream_t s) { if (!enabled || n >= MAXP) return; (void)hipEventRecord(ev[2 * n + 1], s); n++; }
+  void resolve(cjs_stats* st) {
+    double ms = 0; uint64_t e = 0;
+    for (int i = 0; i < n; i++) { float t = 0; if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { ms += t; e += elems[i]; } }
+    if (st && n) { st->ms_bwt_dominant = ms / n; st->bwt_dominant_launches = (uint64_t)n; st->bwt_dominant_bytes = e; }
+    reset();
+  }
+  void reset() { for (int i = 0; i < made; i++) (void)hipEventDestroy(ev[i]); n = made = 0; }
+};
+
 struct BwtWork {
   size_t cap = 0;
   uint64_t* key[2] = {nullptr, nullptr};
@@ -99,8 +121,9 @@ struct BwtWork {
   uint32_t* counters = nullptr;  // 16: [0] survivors [1] groups [8] tile ticket [9] look-back error
   uint32_t* ghist = nullptr;     // [8][256] digit histograms + [8][256] their exclusive scans (onesweep passes)
   uint32_t* h_counters = nullptr;  // pinned host mirror
-  void release_host() { if (h_counters) (void)hipHostFree(h_counters); h_counters = nullptr; }
+  void release_host() { if (h_counters) (void)hipHostFree(h_counters); h_counters = nullptr; lt.reset(); }
   uint32_t hist_tiles = 0, bintot_segs = 0;   // capacity of hist (tiles) and bintot (segments)
+  LaunchTimes lt;                  // dominant-kernel events of the last bwt_run that was given a stats struct
   bool no_large_groups = false;    // per bwt_run: no unresolved group exceeds the tile sorter's limit any more
   // segmented sorts round every block up to whole tiles: room for one extra tile per 64 Ki elements
   static size_t hist_tiles_for(size_t cap) { return (cap + RS_TILE - 1) / RS_TILE + cap / 65536 + 258; }
@@ -113,6 +136,6 @@ struct BwtWork {
 // Suffix-sorts nb blocks (block k = d_T[k*stride .. +n_k), n_k = stride except the last = n_last)
 // and writes the BWT bytes to d_U (same layout) and the primary indices to d_pidx[nb].
 int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t stride, uint32_t n_last,
-            bool cyclic, uint8_t* d_U, uint32_t* d_pidx, cjs_stats* stats);
+            bool cyclic, uint8_t* d_U, uint32_t* d_pidx, cjs_stats* stats, bool resolve_stats = true);
 
 }  // namespace cjs

@@ -21,7 +21,7 @@ struct HuffBufs {
 struct HuffWork {
   size_t max_blocks = 0;
   HuffBufs b{};
-  uint64_t* scalars = nullptr;   // [0] total bits, [1] (u32) stream crc
+  uint64_t* scalars = nullptr;   // [0] total bits, [1] (u32) stream crc, [2] output too small
   static size_t sel_stride_for(uint32_t stride) { return (((size_t)stride + 1 + 49) / 50 + 63) & ~(size_t)63; }
   static size_t bytes_needed(size_t max_blocks, uint32_t stride);
   int carve(Arena& a, size_t max_blocks, uint32_t stride);
@@ -33,6 +33,6 @@ int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A
 int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first, uint32_t count, uint64_t start_bit, int level,
                   int write_header, int write_trailer, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                   const uint32_t* d_asz, const uint8_t* d_alist, const uint32_t* d_block_crc, const uint32_t* d_pidx,
-                  uint32_t* d_out32);
+                  uint32_t* d_out32, size_t out_cap_bytes);    // scalars[2] = 1 and nothing written if the stream does not fit
 
 }  // namespace cjs

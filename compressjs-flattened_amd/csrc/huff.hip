@@ -388,13 +388,16 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
 }
 
 // ------------------------------------------------------------------ bit offsets + stream CRC (one lane, tiny)
+// also the output size check (no host round trip for it): too_small[0] = 1 stops the pack kernels before they write anything
 __global__ void huff_offsets(HuffBufs hb, const uint32_t* __restrict__ block_crc, uint32_t nb, uint32_t first, uint32_t count,
-                             uint64_t start_bit, uint32_t* __restrict__ stream_crc_out) {
+                             uint64_t start_bit, uint32_t* __restrict__ stream_crc_out, uint64_t trailer_bits, uint64_t cap_bytes,
+                             uint64_t* __restrict__ too_small) {
   if (threadIdx.x || blockIdx.x) return;
   (void)first;
   uint64_t bit = start_bit;                         // per-block buffers are indexed relative to `first`
   for (uint32_t k = 0; k < count; k++) { hb.bitoff[k] = bit; bit += hb.bitlen[k]; }
   hb.bitoff[count] = bit;
+  too_small[0] = (bit + trailer_bits + 7) / 8 + 8 > cap_bytes ? 1u : 0u;
   uint32_t c = 0;
   for (uint32_t k = 0; k < nb; k++) c = ((c << 1) | (c >> 31)) ^ block_crc[k];      // Bzip2:2237
   *stream_crc_out = c;
@@ -455,10 +458,12 @@ __device__ void pack_phase(uint32_t count, F item_fn, uint32_t* words, uint32_t*
 __global__ __launch_bounds__(1024) void pack_block(HuffBufs hb, uint32_t first, const uint16_t* __restrict__ Aall, size_t a_stride,
                                                    const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
                                                    const uint8_t* __restrict__ alist_all, const uint32_t* __restrict__ block_crc,
-                                                   const uint32_t* __restrict__ pidx_all, uint32_t* __restrict__ out32) {
+                                                   const uint32_t* __restrict__ pidx_all, uint32_t* __restrict__ out32,
+                                                   const uint64_t* __restrict__ too_small) {
   __shared__ uint32_t words[PK_WORDS];
   __shared__ uint32_t sm[16];
   __shared__ uint32_t used16[17];
+  if (too_small[0]) return;
   __shared__ uint32_t ctab[6 * MAXSYM];
   __shared__ uint8_t ltab[6 * MAXSYM + 4];
   const uint32_t blk = blockIdx.x;                  // relative to `first`; block_crc is absolute
@@ -509,11 +514,12 @@ __global__ __launch_bounds__(1024) void pack_block(HuffBufs hb, uint32_t first, 
 // data (Bzip2:2189-2194): tile `blockIdx.x` of block `blockIdx.y`; its first bit = block start + block bits - data bits +
 // the tile's offset from huff_block.  Interior words are plain stores, the two boundary words are OR-ed.
 __global__ __launch_bounds__(1024) void pack_data(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride, const uint32_t* __restrict__ npos_all,
-                                                  uint32_t* __restrict__ out32) {
+                                                  uint32_t* __restrict__ out32, const uint64_t* __restrict__ too_small) {
   __shared__ uint32_t words[PK_WORDS];
   __shared__ uint32_t sm[16];
   __shared__ uint32_t ctab[6 * MAXSYM];
   __shared__ uint8_t ltab[6 * MAXSYM + 4];
+  if (too_small[0]) return;
   const uint32_t blk = blockIdx.y, tile = blockIdx.x;
   const uint32_t npos = npos_all[blk], nsel = (npos + GSZ - 1) / GSZ;
   if (tile * PD_GROUPS >= nsel) return;
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(1024) void pack_data(HuffBufs hb, const uint16_t* _
 __global__ void pack_frame(HuffBufs hb, uint32_t nb_range_end, int level, int write_header, int write_trailer,
                            const uint32_t* __restrict__ stream_crc, uint32_t* __restrict__ out32, uint64_t* __restrict__ total_bits) {
   if (threadIdx.x || blockIdx.x) return;
+  if (total_bits[2]) { total_bits[0] = hb.bitoff[nb_range_end] + (write_trailer ? 80u : 0u); return; }      // output too small: nothing is written
   if (write_header) atomicOr(&out32[0], __builtin_bswap32(0x425a6830u + (uint32_t)level));   // 'B''Z''h''0'+level
   uint64_t bit = hb.bitoff[nb_range_end];
   if (write_trailer) {
@@ -596,12 +603,13 @@ int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A
 int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first, uint32_t count, uint64_t start_bit, int level,
                   int write_header, int write_trailer, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                   const uint32_t* d_asz, const uint8_t* d_alist, const uint32_t* d_block_crc, const uint32_t* d_pidx,
-                  uint32_t* d_out32) {
+                  uint32_t* d_out32, size_t out_cap_bytes) {
   uint32_t* stream_crc = (uint32_t*)(w.scalars + 1);
-  hipLaunchKernelGGL(huff_offsets, dim3(1), dim3(1), 0, s, w.b, d_block_crc, nb_total, first, count, start_bit, stream_crc);
+  hipLaunchKernelGGL(huff_offsets, dim3(1), dim3(1), 0, s, w.b, d_block_crc, nb_total, first, count, start_bit, stream_crc,
+                     (uint64_t)(write_trailer ? 80 : 0), (uint64_t)out_cap_bytes, w.scalars + 2);
   if (count) {
-    hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32);
-    hipLaunchKernelGGL(pack_data, dim3((unsigned)(w.b.tile_stride - 1), count), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_out32);
+    hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32, w.scalars + 2);
+    hipLaunchKernelGGL(pack_data, dim3((unsigned)(w.b.tile_stride - 1), count), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_out32, w.scalars + 2);
   }
   hipLaunchKernelGGL(pack_frame, dim3(1), dim3(1), 0, s, w.b, count, level, write_header, write_trailer, stream_crc, d_out32, w.scalars);
   CJS_HIP_TRY(hipGetLastError());

@@ -144,61 +144,48 @@ static int compress_core_impl(cjs_ctx* c, const uint8_t* d_in, size_t n, int lev
     ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
   } evp;
   hipEvent_t &ev0 = evp.a, &ev1 = evp.b;
+  const bool stage_times = st && !(st->flags & CJS_STATS_NO_STAGE_TIMES);
   if (st) { memset(st, 0, sizeof *st); CJS_HIP_TRY(hipEventCreate(&ev0)); CJS_HIP_TRY(hipEventCreate(&ev1)); (void)hipEventRecord(ev0, s); }
-  uint32_t nb = 0;
-  if (st) c->timer.start();
-  CJS_TRY(rle1_run(s, c->rle, d_in, n, &nb));
+  uint32_t nb = 0, last_len = 0;
+  if (stage_times) c->timer.start();
+  CJS_TRY(rle1_run(s, c->rle, d_in, n, &nb, &last_len));
   if (total_blocks) *total_blocks = (long)nb;
   if (first < 0 || first > (long)nb) return CJS_E_INVALID_ARG;
   if (count < 0 || first + count > (long)nb) count = (long)nb - first;
   const uint32_t f = (uint32_t)first, cnt = (uint32_t)count;
   if (cnt > c->range_blocks) return CJS_E_INVALID_ARG;
   uint32_t n_last = c->cap;
-  if (cnt && f + cnt == nb) {
-    CJS_HIP_TRY(hipMemcpyAsync(c->h_scalars, c->rle.block_len + (nb - 1), 4, hipMemcpyDeviceToHost, s));
-    CJS_HIP_TRY(hipStreamSynchronize(s));
-    n_last = ((uint32_t*)c->h_scalars)[0];
-  }
+  if (cnt && f + cnt == nb) n_last = last_len;        // (came to the host with the block count)
   // all per-block buffers below are indexed relative to `first`; only rle.block_len / block_crc are absolute
   CJS_TRY(rle1_finish(s, c->rle, d_in, n, f, cnt, c->d_blocks, c->side, c->ev_fork, c->ev_join));
-  if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_rle1 = c->timer.stop(); }
+  if (stage_times) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_rle1 = c->timer.stop(); }
   if (cnt) {
-    if (st) c->timer.start();
-    CJS_TRY(bwt_run(s, c->bwt, c->d_blocks, cnt, c->cap, n_last, true, c->d_U, c->d_pidx, st));
-    if (st) { st->ms_bwt = c->timer.stop(); c->timer.start(); }
+    if (stage_times) c->timer.start();
+    CJS_TRY(bwt_run(s, c->bwt, c->d_blocks, cnt, c->cap, n_last, true, c->d_U, c->d_pidx, st, stage_times));
+    if (stage_times) { st->ms_bwt = c->timer.stop(); c->timer.start(); }
     CJS_TRY(mtf_run(s, c->mtf, c->d_U, cnt, c->rle.block_len + f));
-    if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_mtf = c->timer.stop(); c->timer.start(); }
+    if (stage_times) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_mtf = c->timer.stop(); c->timer.start(); }
     CJS_TRY(huff_tables_run(s, c->huff, cnt, c->mtf.b.A, c->mtf.b.a_stride, c->mtf.b.npos, c->mtf.b.asz, c->mtf.b.freq, c->mtf.b.alist));
-    if (st) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_huff = c->timer.stop(); }
+    if (stage_times) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_huff = c->timer.stop(); }
   }
-  if (st) c->timer.start();
+  if (stage_times) c->timer.start();
   if (cnt && n && c->side) CJS_HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));      // block CRCs (side stream) before the headers are packed
   CJS_HIP_TRY(hipMemsetAsync(d_out, 0, out_cap & ~(size_t)3, s));
   const uint64_t start_bit = framed ? 32 : 0;
-  {  // output size check before any packing: sum of the block bit lengths (small D2H)
-    uint64_t need_bits = start_bit + (framed ? 80 : 0);
-    if (cnt) {
-      uint32_t* hbl = (uint32_t*)malloc(sizeof(uint32_t) * cnt);
-      if (!hbl) return CJS_E_OUT_OF_MEMORY;
-      hipError_t e = hipMemcpyAsync(hbl, c->huff.b.bitlen, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
-      if (e != hipSuccess) { free(hbl); return CJS_E_HIP; }
-      for (uint32_t k = 0; k < cnt; k++) need_bits += hbl[k];
-      free(hbl);
-    }
-    if ((need_bits + 7) / 8 + 8 > (out_cap & ~(size_t)3)) return CJS_E_OUTPUT_TOO_SMALL;
-  }
+  // (the output size check is made on the device, by huff_offsets: no host round trip in front of the packing)
   CJS_TRY(huff_pack_run(s, c->huff, nb, f, cnt, start_bit, level, framed ? 1 : 0, framed ? 1 : 0, c->mtf.b.A, c->mtf.b.a_stride,
-                        c->mtf.b.npos, c->mtf.b.asz, c->mtf.b.alist, c->rle.block_crc, c->d_pidx, (uint32_t*)d_out));
-  CJS_HIP_TRY(hipMemcpyAsync(c->h_scalars, c->huff.scalars, 8, hipMemcpyDeviceToHost, s));
+                        c->mtf.b.npos, c->mtf.b.asz, c->mtf.b.alist, c->rle.block_crc, c->d_pidx, (uint32_t*)d_out, out_cap & ~(size_t)3));
+  CJS_HIP_TRY(hipMemcpyAsync(c->h_scalars, c->huff.scalars, 24, hipMemcpyDeviceToHost, s));
   if (block_crcs && nb) {
     if ((long)nb > crc_cap) return CJS_E_OUTPUT_TOO_SMALL;
     CJS_HIP_TRY(hipMemcpyAsync(block_crcs, c->rle.block_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s));
   }
   CJS_HIP_TRY(hipStreamSynchronize(s));
+  if (c->h_scalars[2]) return CJS_E_OUTPUT_TOO_SMALL;
   *out_bits = c->h_scalars[0];
   if (st) {
-    st->ms_pack = c->timer.stop();
+    if (stage_times) st->ms_pack = c->timer.stop();
+    if (!stage_times && cnt) c->bwt.lt.resolve(st);      // the stream has drained
     (void)hipEventRecord(ev1, s); (void)hipEventSynchronize(ev1);
     float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1);
     st->ms_total = ms;

@@ -30,7 +30,7 @@ struct Rle1Work {
   void release() { if (h_n) (void)hipHostFree(h_n); h_n = nullptr; }
 };
 
-int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host);
+int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host, uint32_t* last_len_host = nullptr);
 int rle1_finish(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t first, uint32_t count, uint8_t* d_blocks,
                 hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 

@@ -694,9 +694,10 @@ __global__ void rle_crc_final(const RleBlock* __restrict__ blocks, const uint32_
   block_crc[k] = ~crc;
 }
 
-__global__ void rle_block_lens(const RleBlock* __restrict__ blocks, const uint32_t* __restrict__ nblocks_p, uint32_t* __restrict__ block_len) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < *nblocks_p) block_len[k] = blocks[k].len;
+__global__ void rle_block_lens(const RleBlock* __restrict__ blocks, uint32_t* nblocks_p, uint32_t* __restrict__ block_len) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nb = nblocks_p[0];
+  if (k < nb) block_len[k] = blocks[k].len;
+  if (k + 1 == nb) nblocks_p[1] = blocks[k].len;      // length of the last block: goes to the host with the count
 }
 
 // ------------------------------------------------------------------------------------------
@@ -738,7 +739,7 @@ int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, c
 
 // Stage 0a: block boundaries of the whole stream d_in[0..N).  Leaves descriptors / lengths on the device,
 // returns the number of blocks in *nblocks_host (syncs the stream).
-int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host) {
+int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host, uint32_t* last_len_host) {
   if (N > w.max_in) return CJS_E_INVALID_ARG;
   if (N == 0) { *nblocks_host = 0; CJS_HIP_TRY(hipMemsetAsync(w.nblocks, 0, 4, s)); return 0; }
   const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
@@ -755,9 +756,10 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32
   hipLaunchKernelGGL(rle_block_lens, dim3((w.max_blocks + 255) / 256), dim3(256), 0, s, w.blocks, w.nblocks, w.block_len);
   CJS_HIP_TRY(hipGetLastError());
   if (!w.h_n) CJS_HIP_TRY(hipHostMalloc((void**)&w.h_n, 16));
-  CJS_HIP_TRY(hipMemcpyAsync(w.h_n, w.nblocks, 4, hipMemcpyDeviceToHost, s));
+  CJS_HIP_TRY(hipMemcpyAsync(w.h_n, w.nblocks, 8, hipMemcpyDeviceToHost, s));
   CJS_HIP_TRY(hipStreamSynchronize(s));
   *nblocks_host = w.h_n[0];
+  if (last_len_host) *last_len_host = w.h_n[0] ? w.h_n[1] : 0u;
   if (getenv("CJS_DEBUG")) {
     uint64_t d[8];
     if (hipMemcpyFromSymbol(d, HIP_SYMBOL(g_walk_dbg), sizeof d) == hipSuccess)

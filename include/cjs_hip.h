@@ -45,7 +45,11 @@ typedef struct cjs_stats {
   uint64_t blocks;
   uint64_t bytes_in, bytes_out;
   uint32_t bwt_rounds;
+  uint32_t flags;         /* IN: CJS_STATS_* (read before the struct is cleared and filled) */
 } cjs_stats;
+/* no stream synchronisation between the stages: ms_rle1 / ms_bwt / ms_mtf / ms_huff / ms_pack stay 0, the rest is filled
+ * (whole-call events, dominant-kernel events, counts).  What bench.py passes inside its timed loop. */
+#define CJS_STATS_NO_STAGE_TIMES 1u
 /* cjs_bwtc_compress fills the same struct with wall-clock times of its two halves: ms_total = whole call, ms_bwt =
  * longest GPU batch (workspace + H2D + BWT + MTF + model), ms_mtf = time until the first step list reached the host,
  * ms_pack = serial range coder over the step lists (host), ms_rle1 = time the coder spent waiting for the GPU. */

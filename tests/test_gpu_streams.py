@@ -59,6 +59,33 @@ def test_device_range_assembly_equals_whole_stream(oracle):
     assert rc == 0 and np.array_equal(stream, want)
 
 
+def test_device_output_too_small_is_refused_without_writing(oracle):
+    # the size check of the device-resident entry point runs on the device (huff_offsets): a buffer that cannot hold the
+    # stream gives CJS_E_OUTPUT_TOO_SMALL and stays untouched past its cleared prefix, one that just fits gives the stream
+    sys.path.insert(0, ROOT)
+    import torch
+    pkg = importlib.import_module("compressjs-flattened_amd")
+    data = recipes.textgen(700000, 9)
+    rc, want = oracle.bzip2_compress(data, 2)
+    assert rc == 0
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(data.copy()).to(dev)
+    ctx = pkg.DeviceContext(0, data.size, 2)
+    d_out = torch.full((want.size + 64,), 0xAB, dtype=torch.uint8, device=dev)
+    small = (want.size // 2) & ~3
+    with pytest.raises(pkg.CjsError) as e:
+        ctx.compress(d_in.data_ptr(), data.size, d_out.data_ptr(), small)
+    assert e.value.errorCode == -33
+    back = d_out.cpu().numpy()
+    assert not back[:small].any() and (back[small:] == 0xAB).all()
+    st = pkg.Stats()
+    st.flags = pkg.Stats.NO_STAGE_TIMES
+    n = ctx.compress(d_in.data_ptr(), data.size, d_out.data_ptr(), (want.size + 8 + 3) & ~3, st)
+    assert n == want.size and np.array_equal(d_out[:n].cpu().numpy(), want)
+    assert st.ms_total > 0 and st.ms_bwt == 0 and st.bwt_dominant_launches > 0 and st.blocks == 4
+    ctx.close()
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_js_front_matches_goldens():
     g = support.load_golden("golden_small.json")

@@ -18,7 +18,8 @@ for r, n in list(zip(rows, names))[start:]:
     gap = (s - t_prev) / 1e3 if t_prev is not None else 0.0
     t_prev = e
     total += d; gaps += max(gap, 0.0)
-    if n.startswith('bwt_gather_keys') or n.startswith('mtf_head_tiles') and line and not line[-1].startswith('mtf'):
+    if (n.startswith('bwt_gather_keys') or (n.startswith('bwt_tile_sort') and not any(x.startswith('gather_keys') for x in line))
+            or n.startswith('mtf_head_tiles') and line and not line[-1].startswith('mtf')):
         print('  '.join(line)); line = []
     line.append('%s %.0f%s' % (n.replace('bwt_', '').replace('rs_', 'r:'), d, ('(+%.0f)' % gap) if gap > 8 else ''))
 print('  '.join(line))
