@@ -117,13 +117,15 @@ __global__ __launch_bounds__(256) void rle_tile_count(const uint8_t* __restrict_
   const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * 16;
   if ((threadIdx.x & 15) == 0) dmod[(size_t)blockIdx.x * 16 + (threadIdx.x >> 4)] = (uint8_t)(p0 < N ? (((bm & 1u) ? 0ull : p0 - rs) % 255) : 0);
   uint32_t cnt = 0;
+  // offset in the run mod 255: one 64-bit remainder per thread, then +1 per byte (0 at a run start)
+  uint32_t dp = p0 < N ? (uint32_t)((p0 - rs) % 255) : 0u;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
     const uint64_t p = p0 + j;
     if (p < N) {
-      if ((bm >> j) & 1u) rs = p;
-      const uint32_t dp = (uint32_t)((p - rs) % 255);
+      if ((bm >> j) & 1u) dp = 0;
       cnt += dp < 3 ? 1u : dp == 3 ? 2u : 0u;
+      dp = dp == 254 ? 0u : dp + 1u;
     }
   }
   uint32_t tot;
@@ -486,15 +488,16 @@ __global__ __launch_bounds__(256) void rle_materialize(const uint8_t* __restrict
   // global c and its exclusive prefix inside the tile
   uint32_t dpg[16], cnt = 0;
   {
-    uint64_t r = rs;
+    uint32_t dp = p0 < N ? (uint32_t)((p0 - rs) % 255) : 0u;      // offset in the run mod 255: one 64-bit remainder per thread
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint64_t p = p0 + j;
       dpg[j] = 255;
       if (p < N) {
-        if ((bm >> j) & 1u) r = p;
-        dpg[j] = (uint32_t)((p - r) % 255);
-        cnt += dpg[j] < 3 ? 1u : dpg[j] == 3 ? 2u : 0u;
+        if ((bm >> j) & 1u) dp = 0;
+        dpg[j] = dp;
+        cnt += dp < 3 ? 1u : dp == 3 ? 2u : 0u;
+        dp = dp == 254 ? 0u : dp + 1u;
       }
     }
   }
