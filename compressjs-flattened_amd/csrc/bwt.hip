@@ -438,27 +438,65 @@ __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ ti
   if (threadIdx.x == 0) { counters[0] = c0; counters[1] = c1; host_mirror[0] = c0; host_mirror[1] = c1; }
 }
 
+// Wave-uniform: global index of the first slot of the class (key >> shift) that runs into slot `base` from the left, inside
+// [seg0, base] (the block is sorted, seg0 = its first slot).  Looks at the 64 slots in front of `base` -- nearly always
+// enough -- and otherwise makes a 64-way search for the lower bound of the class in the block.  Needs all 64 lanes.
+__device__ __forceinline__ uint64_t class_head_before(const uint64_t* __restrict__ key, uint64_t seg0, uint64_t base, int shift, int lane) {
+  if (base == seg0) return base;
+  const uint64_t target = key[base] >> shift;
+  const uint64_t off = base - seg0;
+  const uint32_t back = off < 64u ? (uint32_t)off : 64u;                // slots in front of base, inside the block
+  const bool eq = (uint32_t)lane < back && (key[base - 1u - (uint32_t)lane] >> shift) == target;
+  const uint64_t ne = ~__ballot(eq);
+  const uint32_t m = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;          // slots base-1 .. base-m carry the class
+  if (m < 64u || off <= 64u) return base - m;
+  uint64_t lo = seg0, hi = base - 64u;                                  // key[hi] is known to carry the class
+  while (hi > lo) {
+    const uint64_t len = hi - lo, step = (len + 63u) / 64u, idx = lo + (uint64_t)lane * step;
+    const bool hit = idx >= hi || (key[idx] >> shift) == target;
+    const uint64_t hits = __ballot(hit);
+    const uint32_t j = hits ? (uint32_t)__builtin_ctzll(hits) : 64u;    // first probe inside the class (64: none, it starts behind the last probe)
+    if (!j) { hi = lo; break; }
+    const uint64_t nhi = lo + (uint64_t)j * step;
+    lo += (uint64_t)(j - 1u) * step + 1u;
+    if (j < 64u && nhi < hi) hi = nhi;
+  }
+  return hi;
+}
+
 // regroup: new ranks -> R (scattered 4-byte stores), singletons -> SA, survivors compacted into the next
 // active arrays.  Fully lane-striped: the per-element prefix quantities come from 4096-bit masks
 // (wave ballots) + a 64-word scan, so every global access of a wave touches consecutive addresses.
 // `hm_`: two-sweep scheduling of the scattered rank stores (see HalfMap); everything but the ranks is written by sweep 0.
-template <bool FIRST, bool PACKED>      // FIRST: round 1 - slot a is sorted position a, and there is no previous grouping
+// SWEEP 1 / 2 (round 1, packed records): the two sweeps as two launches with the tile scan between them, and NO counting pass
+// in front -- sweep 1 stores the ranks of the lower half-blocks and leaves the tile counts that bwt_flags would have made
+// (it finds the one class head it cannot see by search: class_head_before); sweep 2 stores the upper half and, with the
+// scanned counts, everything else.
+template <bool FIRST, bool PACKED, int SWEEP = 0>      // FIRST: round 1 - slot a is sorted position a, and there is no previous grouping
 __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                  const uint32_t* __restrict__ pos, uint32_t A, Geom g,
-                                                 const uint32_t* __restrict__ tile_cnt, uint32_t T,
+                                                 uint32_t* tile_cnt, uint32_t T,
                                                  uint32_t* __restrict__ R, uint32_t* __restrict__ SA,
                                                  uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord, HalfMap hm_) {
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
+  __shared__ uint32_t carry_s;
   uint32_t tile, half;
-  if (!half_map(hm_, g.nb, A, T, tile, half)) return;
+  if (SWEEP == 0) { if (!half_map(hm_, g.nb, A, T, tile, half)) return; }
+  else { tile = xcd_tile(blockIdx.x, T); half = SWEEP - 1; if (tile >= T) return; }
   const uint32_t hsplit = hm_.stride >> 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint64_t base = (uint64_t)tile * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
   // every streaming load of the tile is issued up front (one loop of load + LDS store makes the compiler wait per load)
-  const uint32_t sbase = tile_cnt[tile], hbase = tile_cnt[T + tile], carry = tile_cnt[2 * (size_t)T + tile];
+  uint32_t sbase = 0, hbase = 0, carry = 0;
+  if (SWEEP != 1) { sbase = tile_cnt[tile]; hbase = tile_cnt[T + tile]; carry = tile_cnt[2 * (size_t)T + tile]; }
+  else if (w == 0) {
+    const uint64_t seg0 = (uint64_t)((uint32_t)base / g.stride) * g.stride;     // (round 1: slot = sorted position)
+    const uint32_t c = (uint32_t)class_head_before(key, seg0, base, PACKED ? PK_SHIFT : 0, lane) + 1u;
+    if (lane == 0) carry_s = c;
+  }
   uint32_t p16[FIRST ? 1 : 16], v16[PACKED ? 1 : 16];
   {
     uint64_t k16[16];
@@ -513,8 +551,12 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
     uint32_t em = __shfl_up(im, 1, 64);
     if (lane == 0) em = 0;
     wp_s[lane] = is - sv; wp_h[lane] = ih - hd; wp_head[lane] = em;
+    if (SWEEP == 1 && lane == 63) {          // what bwt_flags counts: survivors, surviving heads, (last head index) + 1
+      tile_cnt[tile] = is; tile_cnt[T + tile] = ih; tile_cnt[2 * (size_t)T + tile] = im ? (uint32_t)base + im : 0u;
+    }
   }
   __syncthreads();
+  if (SWEEP == 1) carry = carry_s;
   const uint64_t lt = (1ull << lane) - 1ull, le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
 #pragma unroll
   for (int it = 0; it < 16; it++) {
@@ -539,7 +581,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
       const uint32_t blk = p / g.stride;
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
       if (!keeps_rank && (hm_.halves <= 1 || (uint32_t)(vv >= hsplit) == half)) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
-      if (half) continue;
+      if (SWEEP == 0 ? half != 0 : SWEEP == 1) continue;
       if ((ms >> lane) & 1ull) __builtin_nontemporal_store(vv, SA + p);
       else {
         const uint32_t so = sbase + wp_s[wi] + (uint32_t)__popcll(~ms & lt);
@@ -1048,30 +1090,7 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
   if (tid == 64) sk[0] = t.off ? key[base - 1] : ~0ull;
   if (w == 0) {
     // head of the class of the tile's first slot (global index + 1, as bwt_scan_tiles would have carried it)
-    uint32_t carry = (uint32_t)base + 1u;
-    if (t.off) {
-      const uint64_t target = key[base] >> PK_SHIFT;
-      const uint32_t back = t.off < 64u ? t.off : 64u;                  // slots in front of the tile, inside the block
-      const bool eq = (uint32_t)lane < back && (key[base - 1u - (uint32_t)lane] >> PK_SHIFT) == target;
-      const uint64_t ne = ~__ballot(eq);
-      const uint32_t m = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;      // slots base-1 .. base-m carry the class
-      uint64_t head = base - m;
-      if (m == 64u && t.off > 64u) {                                    // the class is longer: lower bound of target in [seg0, base - 64]
-        uint64_t lo = seg0, hi = base - 64u;                            // key[hi] is known to carry the class
-        while (hi > lo) {
-          const uint64_t len = hi - lo, step = (len + 63u) / 64u, idx = lo + (uint64_t)lane * step;
-          const bool hit = idx >= hi || (key[idx] >> PK_SHIFT) == target;
-          const uint64_t hits = __ballot(hit);
-          const uint32_t j = hits ? (uint32_t)__builtin_ctzll(hits) : 64u;   // first probe inside the class (64: none, it starts behind the last probe)
-          if (!j) { hi = lo; break; }
-          const uint64_t nhi = lo + (uint64_t)j * step;
-          lo += (uint64_t)(j - 1u) * step + 1u;
-          if (j < 64u && nhi < hi) hi = nhi;
-        }
-        head = hi;
-      }
-      carry = (uint32_t)head + 1u;
-    }
+    const uint32_t carry = (uint32_t)class_head_before(key, seg0, base, PK_SHIFT, lane) + 1u;
     if (lane == 0) carry_s = carry;
   }
   // the two leading bytes of every record's suffix: gathers from the block text (L2), independent of everything below
@@ -1369,7 +1388,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   // packed round-1 records (5 bytes + position in one u64, no value array): cyclic, segmented sorts only
   // defaults from same-box kernel-time A/Bs (profiles/r02_*): packed records + two-sweep rank scatter 18.60 -> 18.15 ms per step
   static const bool env_packed = getenv("CJS_R1_PACKED") == nullptr || atoi(getenv("CJS_R1_PACKED")) != 0;
-  static const int env_halves = getenv("CJS_APPLY_HALVES") ? atoi(getenv("CJS_APPLY_HALVES")) : 2;
+  static const int env_halves = getenv("CJS_APPLY_HALVES") ? atoi(getenv("CJS_APPLY_HALVES")) : 3;      // 3: two launches without a counting pass, 2: one launch behind bwt_flags, 0: one sweep
   // two-phase packed sort: bytes 2..6 first, then bytes 0..1 with the class of bytes 2..6 carried as a rank (depth 7)
   // (same-box A/B: 17.9 -> 17.2 ms per step: the seven passes + the record rebuild cost 4.9 ms instead of 2.8, but 61 M instead of
   //  83.5 M suffixes stay unresolved behind them and every suffix-round costs ~55 ps)
@@ -1402,6 +1421,14 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
     } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups, fuse ? &tg : nullptr));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
+    if (rounds == 0 && packed && sweeps && env_halves == 3) {          // two launches, no counting pass (see bwt_apply)
+      const HalfMap hm{2u, 0u, stride};
+      hipLaunchKernelGGL((bwt_apply<true, true, 1>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+      hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
+      hipLaunchKernelGGL((bwt_apply<true, true, 2>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+    } else {
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
     if (rounds == 0) {
@@ -1417,6 +1444,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
                               w.val[1 - c], w.pos[1 - pc], w.gord, hm);
     } else hipLaunchKernelGGL((bwt_apply<false, false>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                               w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride});
+    }
     CJS_HIP_TRY(hipStreamSynchronize(s));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];

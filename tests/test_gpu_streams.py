@@ -335,6 +335,7 @@ def _run_variant(env, n, seed, level):
 
 @pytest.mark.parametrize("env", [{"CJS_R1_PACKED": "0"}, {"CJS_R1_PACKED": "1"}, {"CJS_APPLY_HALVES": "0"}, {"CJS_APPLY_HALVES": "2"},
                                  {"CJS_TILE_SORT": "radix"}, {"CJS_TILE_SORT": "count"}, {"CJS_R1_TWO_PHASE": "1"}, {"CJS_R1_TWO_PHASE": "0"}, {"CJS_NO_TILE_SORT": "1"}, {"CJS_NO_SEGMENTED_SORT": "1"},
+                                 {"CJS_APPLY_HALVES": "3"}, {"CJS_APPLY_HALVES": "2"},
                                  {"CJS_FUSE_GATHER": "0"}, {"CJS_FUSE_GATHER": "0", "CJS_TILE_SORT": "radix"}, {"CJS_FUSE_GATHER": "1", "CJS_TILE_SORT": "count"},
                                  {"CJS_R1_PACKED": "1", "CJS_APPLY_HALVES": "2", "CJS_TILE_SORT": "radix"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
