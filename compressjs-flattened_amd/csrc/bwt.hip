@@ -1260,6 +1260,7 @@ int BwtWork::carve(Arena& a, size_t cap_) {
   ghist = a.take<uint32_t>(16 * 256);
   if (!counters || !ghist) return CJS_E_OUT_OF_MEMORY;
   if (!h_counters) CJS_HIP_TRY(hipHostMalloc((void**)&h_counters, 64));
+  if (!ev_scan) CJS_HIP_TRY(hipEventCreateWithFlags(&ev_scan, hipEventDisableTiming));
   return 0;
 }
 
@@ -1426,11 +1427,13 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
       hipLaunchKernelGGL((bwt_apply<true, true, 1>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                          w.val[1 - c], w.pos[1 - pc], w.gord, hm);
       hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
+      CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
       hipLaunchKernelGGL((bwt_apply<true, true, 2>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                          w.val[1 - c], w.pos[1 - pc], w.gord, hm);
     } else {
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
+    CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
     if (rounds == 0) {
       HalfMap hm{1u, 0u, stride};
       uint32_t grid = xcd_grid(T);
@@ -1445,7 +1448,9 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     } else hipLaunchKernelGGL((bwt_apply<false, false>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                               w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride});
     }
-    CJS_HIP_TRY(hipStreamSynchronize(s));
+    // the host only needs the counters of the tile scan: it waits for THAT kernel and queues the next round behind the regroup
+    // kernel while it runs (a stream synchronisation here left the GPU idle for ~20 us per round)
+    CJS_HIP_TRY(hipEventSynchronize(w.ev_scan));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt] round %u h=%u A=%u bits=%d -> A'=%u groups=%u\n", rounds, h, A, bits, A2, NG);

@@ -121,7 +121,8 @@ struct BwtWork {
   uint32_t* counters = nullptr;  // 16: [0] survivors [1] groups [8] tile ticket [9] look-back error
   uint32_t* ghist = nullptr;     // [8][256] digit histograms + [8][256] their exclusive scans (onesweep passes)
   uint32_t* h_counters = nullptr;  // pinned host mirror
-  void release_host() { if (h_counters) (void)hipHostFree(h_counters); h_counters = nullptr; lt.reset(); }
+  hipEvent_t ev_scan = nullptr;    // recorded behind the tile scan of a round (the host waits for the counters, not for the round)
+  void release_host() { if (h_counters) (void)hipHostFree(h_counters); h_counters = nullptr; if (ev_scan) (void)hipEventDestroy(ev_scan); ev_scan = nullptr; lt.reset(); }
   uint32_t hist_tiles = 0, bintot_segs = 0;   // capacity of hist (tiles) and bintot (segments)
   LaunchTimes lt;                  // dominant-kernel events of the last bwt_run that was given a stats struct
   bool no_large_groups = false;    // per bwt_run: no unresolved group exceeds the tile sorter's limit any more
