@@ -149,6 +149,42 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
   hist[(size_t)tile * 256 + tid] = sum;
 }
 
+// The same counts from a byte per key: the scatter pass in front left the NEXT digit of every key it moved in dig[] (same
+// index as the key), so this pass reads 1 B per key instead of 8.  Aligned 32-bit loads over the tile's byte range.
+template <int HB>       // histogram copies per wave (the zeroing and folding of 4 * 256 * HB counters is most of this kernel's LDS traffic)
+__global__ __launch_bounds__(256) void rs_hist_bytes(const uint8_t* __restrict__ dig, SegGeom sg, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[4 * 256 * HB];
+  const int tid = threadIdx.x;
+  uint32_t* hw = h + (tid >> 6) * 256 * HB + (tid & (HB - 1));
+#pragma unroll
+  for (int i = 0; i < 4 * HB; i++) h[i * 256 + tid] = 0;
+  const uint32_t tile = blockIdx.x;
+  const TileRef t = tile_ref(sg, tile);
+  const uintptr_t a0 = (uintptr_t)(dig + t.base), a1 = a0 + t.nvalid;
+  const uint32_t* al = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
+  uint32_t wv[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const uint32_t wi = (uint32_t)j * 256u + tid;
+    wv[j] = (t.nvalid && (uintptr_t)(al + wi) < a1) ? al[wi] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const uintptr_t wa = (uintptr_t)(al + ((uint32_t)j * 256u + tid));
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (wa + b >= a0 && wa + b < a1) atomicAdd(&hw[((wv[j] >> (8 * b)) & 255u) * HB], 1u);
+  }
+  __syncthreads();
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < HB; r++) sum += h[i * 256 * HB + tid * HB + r];
+  hist[(size_t)tile * 256 + tid] = sum;
+}
+
 // one workgroup per segment: exclusive scan over the segment's tiles of every digit's count (thread = digit; the rows are
 // read coalesced and the loads of a batch are independent, only the running sums are a chain); digit totals -> bintot
 __global__ __launch_bounds__(256) void rs_scan_bins(uint32_t* __restrict__ hist, uint32_t tps, uint32_t* __restrict__ bintot) {
@@ -218,7 +254,8 @@ __device__ __forceinline__ uint32_t rank_step(uint32_t d, uint32_t* __restrict__
 template <typename K, bool GEN, bool NOVAL>
 __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                   K* __restrict__ kout, uint32_t* __restrict__ vout, SegGeom sg, GenSrc gs, int shift,
-                                                  const uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ bintot) {
+                                                  const uint32_t* __restrict__ hist, uint32_t T, const uint32_t* __restrict__ bintot,
+                                                  uint8_t* __restrict__ dig /* next digit of every key, at the key's new index (or null) */) {
   __shared__ __attribute__((aligned(16))) K skey[RS_TILE + 2];
   __shared__ uint32_t sval[NOVAL ? 1 : RS_TILE];
   __shared__ uint32_t wcnt[4][256];
@@ -283,6 +320,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
       const uint32_t dst = goff[(uint32_t)(kk >> shift) & 255u] + j;
       kout[dst] = kk;
       if (!NOVAL) vout[dst] = sval[j];
+      if (dig) dig[dst] = (uint8_t)((uint64_t)kk >> (shift + 8));
     }
   }
 }
@@ -477,7 +515,8 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
                                                  const uint32_t* __restrict__ pos, uint32_t A, Geom g,
                                                  uint32_t* tile_cnt, uint32_t T,
                                                  uint32_t* __restrict__ R, uint32_t* __restrict__ SA,
-                                                 uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord, HalfMap hm_) {
+                                                 uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord, HalfMap hm_,
+                                                 const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U) {
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
@@ -558,6 +597,20 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   __syncthreads();
   if (SWEEP == 1) carry = carry_s;
   const uint64_t lt = (1ull << lane) - 1ull, le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  // BWT bytes of the suffixes this tile resolves (see the store below): all sixteen gathers are issued before the loop
+  uint32_t ub[16];
+  const bool emits = U != nullptr && !(SWEEP == 0 ? half != 0 : SWEEP == 1);
+  if (emits) {
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint32_t e = (uint32_t)it * 256u + tid;
+      const bool sing = e < nvalid && ((m_sg[it * 4 + w] >> lane) & 1ull);
+      const uint32_t p = FIRST ? (uint32_t)(base + e) : p16[FIRST ? 0 : it];
+      const uint32_t vv = PACKED ? ((uint32_t)sk[e + 1] & PK_POS_MASK) : v16[PACKED ? 0 : it];
+      const uint32_t blk = p / g.stride;
+      ub[it] = sing ? (uint32_t)Tx[(size_t)blk * g.stride + (vv ? vv - 1u : blk_len(g, blk) - 1u)] : 0u;
+    }
+  }
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
@@ -582,8 +635,13 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
       if (!keeps_rank && (hm_.halves <= 1 || (uint32_t)(vv >= hsplit) == half)) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
       if (SWEEP == 0 ? half != 0 : SWEEP == 1) continue;
-      if ((ms >> lane) & 1ull) __builtin_nontemporal_store(vv, SA + p);
-      else {
+      if ((ms >> lane) & 1ull) {
+        // a resolved suffix: its BWT byte goes straight to the output row (cyclic form: U[p] = T[suffix - 1], p in sorted-position
+        // order) -- no suffix array is written, and the byte gathers overlap the rest of the regrouping instead of making a pass
+        // of their own at the end; the sentinel form shifts the rows by the primary index, which is only known at the end: SA
+        if (U) U[p] = (uint8_t)ub[it];
+        else __builtin_nontemporal_store(vv, SA + p);
+      } else {
         const uint32_t so = sbase + wp_s[wi] + (uint32_t)__popcll(~ms & lt);
         const uint32_t ho = hbase + wp_h[wi] + (uint32_t)__popcll(mh & ~ms & le);
         __builtin_nontemporal_store(vv, nval + so); __builtin_nontemporal_store(p, npos + so); __builtin_nontemporal_store(ho - 1u, ngord + so);
@@ -1054,8 +1112,12 @@ __global__ __launch_bounds__(256) void bwt_defer_scatter(uint32_t D, const uint6
 }
 
 __global__ __launch_bounds__(256) void bwt_flush_active(uint32_t A, const uint32_t* __restrict__ val, const uint32_t* __restrict__ pos,
-                                                        uint32_t* __restrict__ SA) {
-  for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < A; a += (uint64_t)gridDim.x * 256) SA[pos[a]] = val[a];
+                                                        uint32_t* __restrict__ SA, Geom g, const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U) {
+  for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < A; a += (uint64_t)gridDim.x * 256) {
+    const uint32_t p = pos[a], v = val[a];
+    if (U) { const uint32_t blk = p / g.stride; U[p] = Tx[(size_t)blk * g.stride + (v ? v - 1u : blk_len(g, blk) - 1u)]; }
+    else SA[p] = v;
+  }
 }
 
 // Two-phase round 1 (cyclic, packed records): seven bytes of depth at 8 bytes per record.  Phase 1 sorted every block by
@@ -1267,7 +1329,8 @@ int BwtWork::carve(Arena& a, size_t cap_) {
 template <typename K>
 static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit,
                         LaunchTimes* lt, const SegGeom* seg = nullptr, const GenSrc* gen = nullptr, bool noval = false,
-                        bool first_hist_ready = false) {       // first_hist_ready: w.hist already holds the tile counts of the first digit
+                        bool first_hist_ready = false,         // first_hist_ready: w.hist already holds the tile counts of the first digit
+                        uint8_t* dig = nullptr) {              // dig: byte per key for the next pass's counts (see rs_hist_bytes)
   const uint32_t T1 = (n + RS_TILE - 1) / RS_TILE;
   const SegGeom sg = seg ? *seg : SegGeom{1u, n, n, T1};
   const uint32_t T = sg.nseg * sg.tps;
@@ -1276,7 +1339,14 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
   const GenSrc g0{nullptr, 0, 0, 0};
   for (int shift = lo_bit; shift < hi_bit; shift += 8) {
     const bool first_gen = gen && shift == lo_bit;        // the first pass makes its keys from the block bytes
+    const bool dig_out = dig && shift + 8 < hi_bit;          // a pass follows: leave its digits
     if (first_hist_ready && shift == lo_bit) {}
+    else if (dig && shift != lo_bit) {
+      static const int hb = getenv("CJS_HB_HR") ? atoi(getenv("CJS_HB_HR")) : 4;      // 100 M keys: 59-82 us per pass with 4 copies, 72-85 with 8, 75-130 with 2
+      if (hb == 2) hipLaunchKernelGGL(rs_hist_bytes<2>, dim3(T), dim3(256), 0, s, dig, sg, w.hist);
+      else if (hb == 4) hipLaunchKernelGGL(rs_hist_bytes<4>, dim3(T), dim3(256), 0, s, dig, sg, w.hist);
+      else hipLaunchKernelGGL(rs_hist_bytes<8>, dim3(T), dim3(256), 0, s, dig, sg, w.hist);
+    }
     else if (first_gen) hipLaunchKernelGGL((rs_hist<K, true>), dim3(T), dim3(256), 0, s, kk[cur], sg, *gen, shift, w.hist, T);
     else hipLaunchKernelGGL((rs_hist<K, false>), dim3(T), dim3(256), 0, s, kk[cur], sg, g0, shift, w.hist, T);
     if (sg.tps <= 4 * SB_CHUNK) hipLaunchKernelGGL(rs_scan_bins, dim3(sg.nseg), dim3(256), 0, s, w.hist, sg.tps, w.bintot);
@@ -1291,7 +1361,7 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
       }
     }
     if (lt) lt->begin(s, n);
-#define RS_SCATTER(GEN_, NOVAL_, G_) hipLaunchKernelGGL((rs_scatter<K, GEN_, NOVAL_>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, G_, shift, w.hist, T, w.bintot)
+#define RS_SCATTER(GEN_, NOVAL_, G_) hipLaunchKernelGGL((rs_scatter<K, GEN_, NOVAL_>), dim3(T), dim3(256), 0, s, kk[cur], vv[cur], kk[1 - cur], vv[1 - cur], sg, G_, shift, w.hist, T, w.bintot, dig_out ? dig : nullptr)
     if (noval) { if (first_gen) RS_SCATTER(true, true, *gen); else RS_SCATTER(false, true, g0); }
     else { if (first_gen) RS_SCATTER(true, false, *gen); else RS_SCATTER(false, false, g0); }
 #undef RS_SCATTER
@@ -1341,7 +1411,7 @@ static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int
     CJS_HIP_TRY(hipGetLastError());
     return 0;
   }
-  CJS_HIP_TRY(hipMemsetAsync(dflag, 1, A, s));
+  dev_fill(s, dflag, 1, A);
   launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag, ngroups, tg);
   hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, tcount);
   hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2, w.h_counters + 2);      // the kernel writes the pinned mirror itself
@@ -1376,7 +1446,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   LaunchTimes& lt = w.lt; lt.reset(); lt.enabled = stats != nullptr;
 
   int c = 0, pc = 0;        // current key/val buffer, current pos buffer
-  CJS_HIP_TRY(hipMemsetAsync(w.counters, 0, 64, s));
+  dev_fill(s, w.counters, 0, 64);
   // round 1 sorts by the leading symbols.  Segmented (normal case): one segment per block, keys generated from the
   // block bytes in the first pass, 7 symbols + the block parity.  Fallback (more tiles/segments than the workspace
   // was carved for, e.g. many tiny blocks): keys materialised with the block id on top, sorted as one array.
@@ -1394,6 +1464,8 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   // (same-box A/B: 17.9 -> 17.2 ms per step: the seven passes + the record rebuild cost 4.9 ms instead of 2.8, but 61 M instead of
   //  83.5 M suffixes stay unresolved behind them and every suffix-round costs ~55 ps)
   static const bool env_two_phase = getenv("CJS_R1_TWO_PHASE") == nullptr || atoi(getenv("CJS_R1_TWO_PHASE")) != 0;
+  // the scatter passes of the packed sort leave the next digit of every key as a byte for the next pass's counts (CJS_R1_DIG=0: counts from the keys)
+  static const bool env_dig = getenv("CJS_R1_DIG") == nullptr || atoi(getenv("CJS_R1_DIG")) != 0;
   const bool packed = env_packed && segmented && cyclic;
   const bool two_phase = packed && env_two_phase;
   if (packed) nsym = two_phase ? 7 : 5;
@@ -1409,14 +1481,19 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   static const bool env_fuse = getenv("CJS_FUSE_GATHER") == nullptr || atoi(getenv("CJS_FUSE_GATHER")) != 0;
   bool fuse = false;
   TsGather tg{nullptr, nullptr, nullptr, 0u, 0, g};
+  // cyclic form: the regroup kernels write the BWT bytes of the suffixes they resolve themselves (CJS_DIRECT_EMIT=0: suffix array + bwt_emit)
+  static const bool env_direct = getenv("CJS_DIRECT_EMIT") == nullptr || atoi(getenv("CJS_DIRECT_EMIT")) != 0;
+  const bool direct = cyclic && env_direct;
+  const uint8_t* dT = direct ? d_T : nullptr;
+  uint8_t* dU = direct ? d_U : nullptr;
   for (;;) {
     if (rounds == 0) {
       if (packed) {
-        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true)));
+        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true, false, env_dig ? w.dflag : nullptr)));
         if (two_phase) {
           hipLaunchKernelGGL(bwt_phase2_records, dim3(sg.nseg * sg.tps), dim3(256), 0, s, w.key[c], sg, d_T, w.hist, w.key[1 - c]);
           c = 1 - c;
-          CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true, true)));
+          CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true, true, env_dig ? w.dflag : nullptr)));
         }
       } else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
@@ -1425,11 +1502,11 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     if (rounds == 0 && packed && sweeps && env_halves == 3) {          // two launches, no counting pass (see bwt_apply)
       const HalfMap hm{2u, 0u, stride};
       hipLaunchKernelGGL((bwt_apply<true, true, 1>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                         w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
       hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
       CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
       hipLaunchKernelGGL((bwt_apply<true, true, 2>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                         w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
     } else {
     hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
@@ -1442,11 +1519,11 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
         grid = 8u * ((nb + 7u) / 8u) * 2u * hm.slots;
       }
       if (packed) hipLaunchKernelGGL((bwt_apply<true, true>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                                     w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+                                     w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
       else hipLaunchKernelGGL((bwt_apply<true, false>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                              w.val[1 - c], w.pos[1 - pc], w.gord, hm);
+                              w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
     } else hipLaunchKernelGGL((bwt_apply<false, false>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride});
+                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride}, dT, dU);
     }
     // the host only needs the counters of the tile scan: it waits for THAT kernel and queues the next round behind the regroup
     // kernel while it runs (a stream synchronisation here left the GPU idle for ~20 us per round)
@@ -1458,7 +1535,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     A = A2; ngroups = NG;
     if (A == 0) break;
     if (cyclic && h >= max_n) {     // only groups of equal rotations are left
-      hipLaunchKernelGGL(bwt_flush_active, dim3((A + 255) / 256), dim3(256), 0, s, A, w.val[c], w.pos[pc], w.SA);
+      hipLaunchKernelGGL(bwt_flush_active, dim3((A + 255) / 256), dim3(256), 0, s, A, w.val[c], w.pos[pc], w.SA, g, dT, dU);
       break;
     }
     if (rounds > 40) return CJS_E_HIP;    // cannot happen: depth doubles every round
@@ -1472,7 +1549,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     bits = 20 + bits_for(NG ? NG - 1 : 0);
   }
   hipLaunchKernelGGL(bwt_pidx, dim3(nb), dim3(256), 0, s, g, (int)cyclic, (int)(A != 0), w.R, d_pidx);
-  {
+  if (!direct) {
     const uint32_t Tn = (M + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(bwt_emit, dim3(xcd_grid(Tn)), dim3(256), 0, s, d_T, g, (int)cyclic, M, w.SA, w.R, d_U, Tn);
   }

@@ -29,7 +29,8 @@ struct HuffWork {
 
 int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                     const uint32_t* d_asz, const uint32_t* d_freq, const uint8_t* d_alist);
-// Packs blocks [first, first+count) starting at absolute bit `start_bit` of d_out32 (which must be zeroed).
+// Packs blocks [first, first+count) starting at absolute bit `start_bit` of d_out32 (the part the stream occupies is
+// zeroed here, the bits in front of start_bit included).
 int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first, uint32_t count, uint64_t start_bit, int level,
                   int write_header, int write_trailer, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                   const uint32_t* d_asz, const uint8_t* d_alist, const uint32_t* d_block_crc, const uint32_t* d_pidx,

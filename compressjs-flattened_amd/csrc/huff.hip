@@ -403,6 +403,17 @@ __global__ void huff_offsets(HuffBufs hb, const uint32_t* __restrict__ block_crc
   *stream_crc_out = c;
 }
 
+// zeroes the part of the output the stream will occupy (the pack kernels OR their boundary words into it): the stream end is
+// known on the device (bitoff[count]); the rest of the caller's buffer is left as it is
+__global__ __launch_bounds__(256) void pack_zero_output(HuffBufs hb, uint32_t count, uint64_t trailer_bits, uint32_t* __restrict__ out32, uint64_t cap_bytes,
+                                                        const uint64_t* __restrict__ too_small) {
+  if (too_small[0]) return;
+  uint64_t bytes = (hb.bitoff[count] + trailer_bits + 7) / 8 + 16;
+  if (bytes > cap_bytes) bytes = cap_bytes;
+  const uint64_t nw = bytes / 4;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * 256) out32[i] = 0;
+}
+
 // ------------------------------------------------------------------ bit packing
 // Put `nbits` (<= 64) of `val` at absolute stream bit `bit` into LDS words indexed from word0.
 __device__ __forceinline__ void put_bits(uint32_t* words, uint64_t word0, uint64_t bit, uint64_t val, uint32_t nbits) {
@@ -607,6 +618,7 @@ int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first,
   uint32_t* stream_crc = (uint32_t*)(w.scalars + 1);
   hipLaunchKernelGGL(huff_offsets, dim3(1), dim3(1), 0, s, w.b, d_block_crc, nb_total, first, count, start_bit, stream_crc,
                      (uint64_t)(write_trailer ? 80 : 0), (uint64_t)out_cap_bytes, w.scalars + 2);
+  hipLaunchKernelGGL(pack_zero_output, dim3(4096), dim3(256), 0, s, w.b, count, (uint64_t)(write_trailer ? 80 : 0), d_out32, (uint64_t)out_cap_bytes, w.scalars + 2);
   if (count) {
     hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32, w.scalars + 2);
     hipLaunchKernelGGL(pack_data, dim3((unsigned)(w.b.tile_stride - 1), count), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_out32, w.scalars + 2);

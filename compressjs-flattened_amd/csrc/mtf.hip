@@ -338,7 +338,7 @@ int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const ui
   const uint32_t tpb = (w.stride + MT_TILE - 1) / MT_TILE;
   if (tpb > 1024 || (size_t)tpb > (size_t)w.b.seg_stride * 256) return CJS_E_INVALID_ARG;
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(w.b.segkeys);
-  CJS_HIP_TRY(hipMemsetAsync(w.b.freq, 0, (size_t)nb * 258 * 4, s));
+  dev_fill(s, w.b.freq, 0, (size_t)nb * 258 * 4);
   hipLaunchKernelGGL(mtf_head_tiles<false>, dim3(tpb, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b, tcnt, tpb, w.b.freq);
   hipLaunchKernelGGL(mtf_head_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tpb, w.b.freq);
   hipLaunchKernelGGL(mtf_head_tiles<true>, dim3(tpb, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b, tcnt, tpb, w.b.freq);
@@ -347,7 +347,7 @@ int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const ui
   hipLaunchKernelGGL(mtf_seg_scan, dim3(nb), dim3(256), 0, s, w.b);
   hipLaunchKernelGGL(mtf_chunk_lists, dim3(max_segs, nb), dim3(1024), 0, s, w.b);
   hipLaunchKernelGGL(mtf_replay, dim3((max_chunks + 255) / 256, nb), dim3(256), 0, s, w.stride, w.b);
-  CJS_HIP_TRY(hipMemsetAsync(w.b.freq, 0, (size_t)nb * 258 * 4, s));
+  dev_fill(s, w.b.freq, 0, (size_t)nb * 258 * 4);
   hipLaunchKernelGGL(mtf_emit_tiles<false>, dim3(tpb, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpb);
   hipLaunchKernelGGL(mtf_emit_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tpb);
   hipLaunchKernelGGL(mtf_emit_tiles<true>, dim3(tpb, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpb);

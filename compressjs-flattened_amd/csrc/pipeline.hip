@@ -170,7 +170,6 @@ static int compress_core_impl(cjs_ctx* c, const uint8_t* d_in, size_t n, int lev
   }
   if (stage_times) c->timer.start();
   if (cnt && n && c->side) CJS_HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));      // block CRCs (side stream) before the headers are packed
-  CJS_HIP_TRY(hipMemsetAsync(d_out, 0, out_cap & ~(size_t)3, s));
   const uint64_t start_bit = framed ? 32 : 0;
   // (the output size check is made on the device, by huff_offsets: no host round trip in front of the packing)
   CJS_TRY(huff_pack_run(s, c->huff, nb, f, cnt, start_bit, level, framed ? 1 : 0, framed ? 1 : 0, c->mtf.b.A, c->mtf.b.a_stride,

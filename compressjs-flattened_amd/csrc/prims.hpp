@@ -139,4 +139,18 @@ __device__ __forceinline__ T block_sum(T v, T* smem) {
   return r;
 }
 
+// Device fill on the caller's stream (hipMemsetAsync goes through the runtime's blit path: on this stack its fill kernel
+// starts 30-90 us after the kernel in front of it; a plain launch follows within a few us).  `p` 16-byte aligned; the bytes
+// up to the next multiple of 16 behind `bytes` are written too (every workspace array is padded to 256 bytes).
+static __global__ __launch_bounds__(256) void dev_fill_kernel(uint4* __restrict__ p, uint32_t word, size_t n16) {
+  const uint4 v = make_uint4(word, word, word, word);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+static inline void dev_fill(hipStream_t s, void* p, uint8_t byte, size_t bytes) {
+  const size_t n16 = (bytes + 15) / 16;
+  if (!n16) return;
+  const size_t wg = (n16 + 255) / 256;
+  hipLaunchKernelGGL(dev_fill_kernel, dim3((unsigned)(wg < 4096 ? wg : 4096)), dim3(256), 0, s, (uint4*)p, 0x01010101u * byte, n16);
+}
+
 }  // namespace cjs

@@ -61,7 +61,7 @@ def test_device_range_assembly_equals_whole_stream(oracle):
 
 def test_device_output_too_small_is_refused_without_writing(oracle):
     # the size check of the device-resident entry point runs on the device (huff_offsets): a buffer that cannot hold the
-    # stream gives CJS_E_OUTPUT_TOO_SMALL and stays untouched past its cleared prefix, one that just fits gives the stream
+    # stream gives CJS_E_OUTPUT_TOO_SMALL and stays untouched, one that just fits gives the stream
     sys.path.insert(0, ROOT)
     import torch
     pkg = importlib.import_module("compressjs-flattened_amd")
@@ -77,7 +77,7 @@ def test_device_output_too_small_is_refused_without_writing(oracle):
         ctx.compress(d_in.data_ptr(), data.size, d_out.data_ptr(), small)
     assert e.value.errorCode == -33
     back = d_out.cpu().numpy()
-    assert not back[:small].any() and (back[small:] == 0xAB).all()
+    assert (back == 0xAB).all()
     st = pkg.Stats()
     st.flags = pkg.Stats.NO_STAGE_TIMES
     n = ctx.compress(d_in.data_ptr(), data.size, d_out.data_ptr(), (want.size + 8 + 3) & ~3, st)
