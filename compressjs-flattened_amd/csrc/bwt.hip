@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
 #pragma unroll
     for (int it = 0; it < 16; it++) {
       const uint32_t p = (uint32_t)k16[it] & PK_POS_MASK;
-      b01[it] = ((uint32_t)tx[p] << 8) | tx[p + 1 < n ? p + 1 : 0];
+      b01[it] = ((uint32_t)tx[p] << 8) | tx[p + 1 < n ? p + 1 : 0];          // (one unaligned 16-bit load instead: 720 -> 900 us)
     }
   }
 #pragma unroll

@@ -15,11 +15,14 @@ struct HuffBufs {
   uint64_t* bitoff;   // [nb+1] absolute bit offset of each block in the output
   uint32_t* databits; // [nb] bits of the block's symbol data (the last part of the block)
   uint32_t* tileoff;  // [nb][tile_stride] bit offset of every 80-group (4000-symbol) tile inside the symbol data
+  uint8_t* wl;        // [nb][6][264] code lengths between the kernels of the split refinement
+  uint32_t* wfreq;    // [nb][6][260] symbol counts per table, same
   size_t sel_stride, tile_stride;
 };
 
 struct HuffWork {
   size_t max_blocks = 0;
+  uint32_t max_stride = 0;
   HuffBufs b{};
   uint64_t* scalars = nullptr;   // [0] total bits, [1] (u32) stream crc, [2] output too small
   static size_t sel_stride_for(uint32_t stride) { return (((size_t)stride + 1 + 49) / 50 + 63) & ~(size_t)63; }

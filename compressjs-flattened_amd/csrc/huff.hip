@@ -28,7 +28,7 @@ __device__ uint64_t g_huff_clk[32];
 // ------------------------------------------------------------------ allocator (lane 0, LDS array)
 // a[] entries below the root are extended parent pointers p or p + len (p < len), so "% len" is one conditional subtract
 __device__ __forceinline__ int ha_mod(int x, int len) { return x >= len ? x - len : x; }
-__device__ int ha_first(const int* a, int len, int i, int nodes_to_move) {          // Bzip2:1135-1156
+__device__ __forceinline__ int ha_first(const int* a, int len, int i, int nodes_to_move) {          // Bzip2:1135-1156
   const int limit = i;
   int k = len - 2;
   while (i >= nodes_to_move && ha_mod(a[i], len) > limit) { k = i; i -= (limit - i + 1); }
@@ -39,7 +39,7 @@ __device__ int ha_first(const int* a, int len, int i, int nodes_to_move) {      
   }
   return k;
 }
-__device__ void ha_alloc(int* a, int len, int maxlen) {                             // Bzip2:1275-1298
+__device__ __forceinline__ void ha_alloc(int* a, int len, int maxlen) {                             // Bzip2:1275-1298
   if (len == 2) { a[1] = 1; a[0] = 1; return; }
   if (len == 1) { a[0] = 1; return; }
   // pass 1: extended parent pointers (Bzip2:1162-1186)
@@ -91,8 +91,99 @@ __device__ void ha_alloc(int* a, int len, int maxlen) {                         
   }
 }
 
+// ---- the same allocator with the node array in the wave's registers (entry i = register i / 64 of lane i % 64) and every
+// index, weight and loop variable wave-uniform: reads are v_readlane, writes a compare + select, the control flow is scalar.  The
+// LDS form above runs on one lane and waits ~100+ cycles for every dependent a[i]; here an access costs a few cycles
+// (build of one text table, 100 symbols: 47 -> see DESIGN us).  Same passes, same tie-breaking (Bzip2:1135-1298).
+struct HaRegs { int v[5]; };           // 320 entries >= MAXSYM
+__device__ __forceinline__ int hr_get(const HaRegs& A, int i) {
+  const int l = i & 63, hi = i >> 6;
+  const int r0 = __builtin_amdgcn_readlane(A.v[0], l), r1 = __builtin_amdgcn_readlane(A.v[1], l);
+  if (hi < 2) return hi ? r1 : r0;
+  const int r2 = __builtin_amdgcn_readlane(A.v[2], l), r3 = __builtin_amdgcn_readlane(A.v[3], l), r4 = __builtin_amdgcn_readlane(A.v[4], l);
+  return hi == 2 ? r2 : hi == 3 ? r3 : r4;
+}
+__device__ __forceinline__ void hr_set(HaRegs& A, int i, int x) {       // (no v_writelane builtin in this compiler: compare + select)
+  const int hi = i >> 6;
+  const bool me = lane_id() == (i & 63);
+  if (hi == 0) A.v[0] = me ? x : A.v[0];
+  else if (hi == 1) A.v[1] = me ? x : A.v[1];
+  else if (hi == 2) A.v[2] = me ? x : A.v[2];
+  else if (hi == 3) A.v[3] = me ? x : A.v[3];
+  else A.v[4] = me ? x : A.v[4];
+}
+// a[lo..hi] = x (all lanes at once)
+__device__ __forceinline__ void hr_fill(HaRegs& A, int lo, int hi, int x) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < 5; k++) { const int idx = k * 64 + lane; if (idx >= lo && idx <= hi) A.v[k] = x; }
+}
+__device__ __forceinline__ int hr_first(const HaRegs& A, int len, int i, int nodes_to_move) {
+  const int limit = i;
+  int k = len - 2;
+  while (i >= nodes_to_move && ha_mod(hr_get(A, i), len) > limit) { k = i; i -= (limit - i + 1); }
+  if (i < nodes_to_move - 1) i = nodes_to_move - 1;
+  while (k > i + 1) {
+    const int mid = (i + k) >> 1;
+    if (ha_mod(hr_get(A, mid), len) > limit) k = mid; else i = mid;
+  }
+  return k;
+}
+__device__ __forceinline__ void hr_alloc(HaRegs& A, int len, int maxlen) {
+  if (len == 2) { hr_set(A, 1, 1); hr_set(A, 0, 1); return; }
+  if (len == 1) { hr_set(A, 0, 1); return; }
+  hr_set(A, 0, hr_get(A, 0) + hr_get(A, 1));
+  {
+    int head = 0, top = 2;
+    int H = hr_get(A, 0), Hn = 0;
+    int T = top < len ? hr_get(A, top) : 0, Tn = top + 1 < len ? hr_get(A, top + 1) : 0;
+    for (int tail = 1; tail < len - 1; tail++) {
+      int w;
+      if (top >= len || H < T) { w = H; hr_set(A, head++, tail); H = Hn; if (head + 1 < tail) Hn = hr_get(A, head + 1); }
+      else { w = T; top++; T = Tn; if (top + 1 < len) Tn = hr_get(A, top + 1); }
+      if (top >= len || (head < tail && H < T)) { w += H; hr_set(A, head++, tail + len); H = Hn; if (head + 1 < tail) Hn = hr_get(A, head + 1); }
+      else { w += T; top++; T = Tn; if (top + 1 < len) Tn = hr_get(A, top + 1); }
+      hr_set(A, tail, w);
+      if (head == tail) H = w; else if (head + 1 == tail) Hn = w;
+    }
+  }
+  int reloc = len - 2;
+  for (int depth = 1; depth < maxlen - 1 && reloc > 1; depth++) reloc = hr_first(A, len, reloc - 1, 0);
+  if (ha_mod(hr_get(A, 0), len) >= reloc) {
+    int first = len - 2, next = len - 1;
+    for (int depth = 1, avail = 2; avail > 0; depth++) {
+      const int last = first;
+      first = hr_first(A, len, last - 1, 0);
+      const int cnt = avail - (last - first);
+      if (cnt > 0) { hr_fill(A, next - cnt + 1, next, depth); next -= cnt; }
+      avail = (last - first) << 1;
+    }
+  } else {
+    const unsigned rm1 = (unsigned)(reloc - 1);
+    const int insert_depth = maxlen - (rm1 ? 32 - __builtin_clz(rm1) : 0);
+    int first = len - 2, next = len - 1;
+    int depth = insert_depth == 1 ? 2 : 1;
+    int left = insert_depth == 1 ? reloc - 2 : reloc;
+    for (int avail = depth << 1; avail > 0; depth++) {
+      const int last = first;
+      first = first <= reloc ? first : hr_first(A, len, last - 1, reloc);
+      int offset = 0;
+      if (depth >= insert_depth) { offset = 1 << (depth - insert_depth); if (left < offset) offset = left; }
+      else if (depth == insert_depth - 1) { offset = 1; if (hr_get(A, first) == last) first++; }
+      const int cnt = avail - (last - first + offset);
+      if (cnt > 0) { hr_fill(A, next - cnt + 1, next, depth); next -= cnt; }
+      left -= offset;
+      avail = (last - first + offset) << 1;
+    }
+  }
+}
+
 // One wave builds one table: freq[0..n) -> lens[0..n).  key/work are per-table LDS scratch (n entries).
-__device__ void build_table_wave(const uint32_t* freq, uint8_t* lens, uint32_t* key, int* work, int n) {
+// (forced inline: as a call the LDS pointers are generic and every access a flat_load / flat_store)
+#ifndef CJS_HA_REGS
+#define CJS_HA_REGS 1
+#endif
+__device__ __forceinline__ void build_table_wave(const uint32_t* freq, uint8_t* lens, uint32_t* key, int* work, int n) {
   const int lane = lane_id();
   for (int i = lane; i < n; i += 64) key[i] = (freq[i] << 9) | (uint32_t)i;       // Bzip2:1881-1883
   __builtin_amdgcn_wave_barrier();
@@ -111,7 +202,18 @@ __device__ void build_table_wave(const uint32_t* freq, uint8_t* lens, uint32_t* 
   for (int t = 0, i = lane; t < 5; t++, i += 64) if (i < n) work[rk[t]] = (int)(freq[i]);   // sortedFreq
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
+#if CJS_HA_REGS
+  {
+    HaRegs A;
+#pragma unroll
+    for (int t = 0; t < 5; t++) A.v[t] = lane + 64 * t < n ? work[lane + 64 * t] : 0;
+    hr_alloc(A, __builtin_amdgcn_readfirstlane(n), MAX_BITS);
+#pragma unroll
+    for (int t = 0; t < 5; t++) if (lane + 64 * t < n) work[lane + 64 * t] = A.v[t];
+  }
+#else
   if (lane == 0) ha_alloc(work, n, MAX_BITS);
+#endif
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
   for (int t = 0, i = lane; t < 5; t++, i += 64) if (i < n) lens[i] = (uint8_t)work[rk[t]];
@@ -135,7 +237,9 @@ struct HuffShared {
 // loads (512 groups = 51,200 bytes per step); lane g then reads its 25 dwords at a 25-dword stride (no bank aliasing).
 constexpr int AS_GROUPS = 512;
 __device__ void assign_selectors(HuffShared& S, uint32_t* __restrict__ stage /* AS_GROUPS*25 dwords */, const uint16_t* __restrict__ A,
-                                 uint32_t npos, uint32_t nsel, int ng, uint8_t* __restrict__ sel, uint16_t* __restrict__ bcost) {
+                                 uint32_t npos, uint32_t nsel, int ng, uint8_t* __restrict__ sel, uint16_t* __restrict__ bcost,
+                                 uint32_t g_lo = 0, uint32_t g_hi = 0xFFFFFFFFu /* groups [g_lo, g_hi): a multiple of AS_GROUPS each */) {
+  if (g_hi < nsel) nsel = g_hi;
   for (int s = threadIdx.x; s < MAXSYM; s += 1024) {
     uint64_t pk = 0;
     for (int j = 0; j < ng; j++) pk |= (uint64_t)S.lens[j][s] << (10 * j);
@@ -146,9 +250,9 @@ __device__ void assign_selectors(HuffShared& S, uint32_t* __restrict__ stage /* 
   constexpr int NPRE = (AS_GROUPS * 25 + 1023) / 1024;                 // 13 dwords per lane and step
   uint32_t pre[NPRE];                                                  // next step's symbols: loaded while this step is costed
 #pragma unroll
-  for (int j = 0; j < NPRE; j++) { const uint32_t i = (uint32_t)j * 1024u + threadIdx.x; pre[j] = (i < AS_GROUPS * 25 && i < ndw) ? A32[i] : 0u; }
+  for (int j = 0; j < NPRE; j++) { const uint32_t i = (uint32_t)j * 1024u + threadIdx.x; pre[j] = (i < AS_GROUPS * 25 && g_lo * 25 + i < ndw) ? A32[g_lo * 25 + i] : 0u; }
   const uint32_t half = threadIdx.x & 1u, gl = threadIdx.x >> 1;       // two lanes per group: dwords [0,13) and [13,25)
-  for (uint32_t g0 = 0; g0 < nsel; g0 += AS_GROUPS) {
+  for (uint32_t g0 = g_lo; g0 < nsel; g0 += AS_GROUPS) {
     __syncthreads();                                                   // previous step's readers are done (first step: packed[] is complete)
 #pragma unroll
     for (int j = 0; j < NPRE; j++) { const uint32_t i = (uint32_t)j * 1024u + threadIdx.x; if (i < AS_GROUPS * 25) stage[i] = pre[j]; }
@@ -184,116 +288,83 @@ __device__ void assign_selectors(HuffShared& S, uint32_t* __restrict__ stage /* 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride,
-                                                   const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
-                                                   const uint32_t* __restrict__ freq_all, const uint8_t* __restrict__ alist_all, int dbg) {
-  __shared__ HuffShared S;
-  __shared__ uint32_t stage[AS_GROUPS * 25];
-  const uint32_t blk = blockIdx.x;
-  const uint32_t npos = npos_all[blk], asz = asz_all[blk];
-  const int n = (int)asz + 2;
-  const uint16_t* A = Aall + (size_t)blk * a_stride;
-  uint8_t* sel = hb.sel + (size_t)blk * hb.sel_stride;
-  uint8_t* selj = hb.selj + (size_t)blk * hb.sel_stride;
-  uint16_t* bcost = hb.bcost + (size_t)blk * hb.sel_stride;
-  const uint32_t nsel = (npos + GSZ - 1) / GSZ;
-  const int target = npos >= 2400 ? 6 : npos >= 1200 ? 5 : npos >= 600 ? 4 : npos >= 200 ? 3 : 2;   // Bzip2:2150
-  const int w = wave_id();
+// optimizeHuffmanGroups, the split of one refinement (Bzip2:2012-2042): the most used table's groups are cut at the median
+// cost (stable inside the median bin, Q16); the upper half moves to the new table ng
+__device__ void median_split(HuffShared& S, uint8_t* __restrict__ sel, const uint16_t* __restrict__ bcost, uint32_t nsel, int ng) {
+  if (threadIdx.x < 8) S.counts[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t g = threadIdx.x; g < nsel; g += 1024) atomicAdd(&S.counts[sel[g]], 1u);
+  S.chist[threadIdx.x] = 0;
+  __syncthreads();
+  int which = 0;
+  for (int j = 1; j < ng; j++) if (S.counts[j] > S.counts[which]) which = j;      // indexOf(max): first
+  const uint32_t nsp = S.counts[which], m = nsp >> 1;
+  for (uint32_t g = threadIdx.x; g < nsel; g += 1024) if (sel[g] == which) atomicAdd(&S.chist[bcost[g] & 1023u], 1u);
+  __syncthreads();
+  {
+    const uint32_t hv = S.chist[threadIdx.x];
+    uint32_t tot;
+    const uint32_t cum = block_excl_sum<1024>(hv, S.sm, tot);
+    if (hv && cum <= m && m < cum + hv) { S.misc[0] = threadIdx.x; S.misc[1] = cum; }
+    __syncthreads();
+  }
+  const uint32_t cstar = S.misc[0], cumstar = S.misc[1];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nsel; base += 1024) {        // stable order inside the median cost bin (Q16)
+    const uint32_t g = base + threadIdx.x;
+    uint32_t f = 0, mine = 0xFFFFu;
+    if (g < nsel && sel[g] == which) { mine = bcost[g]; f = mine == cstar; }
+    uint32_t tot;
+    const uint32_t ex = block_excl_sum<1024>(f, S.sm, tot);
+    if (g < nsel && mine != 0xFFFFu) {
+      if (mine > cstar || (f && cumstar + carry + ex >= m)) sel[g] = (uint8_t)ng;
+    }
+    carry += tot;
+  }
+}
 
-  HB_MARK(0);
-  // initial tables: global frequencies and flat (Bzip2:2155-2157)
-  for (int i = threadIdx.x; i < n; i += 1024) { S.freq[0][i] = freq_all[(size_t)blk * 258 + i]; S.freq[1][i] = 1; }
+// symbol counts per table under the current selectors (Bzip2:2043-2048) of symbols [i_lo, i_hi) (i_lo a multiple of 8) into
+// eight replicas of [6][260] counters in `stage` (zeroed here): MTF output is dominated by a few symbols, the replicas (by
+// lane) keep the same-address LDS atomics apart; the caller sums them
+__device__ void count_symbols(uint32_t* __restrict__ stage, const uint16_t* __restrict__ A, const uint8_t* __restrict__ sel,
+                              uint32_t npos, uint32_t i_lo, uint32_t i_hi) {
+  for (int i = threadIdx.x; i < 8 * 6 * 260; i += 1024) stage[i] = 0;
   __syncthreads();
-  if (w < 2) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
-  __syncthreads();
-  int ng = 2;
-  HB_MARK(1);
-  while (ng < target) {                                                             // Bzip2:2012-2053
-    assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);
-    if (ng == 2) HB_MARK(2);
-    if (threadIdx.x < 8) S.counts[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t g = threadIdx.x; g < nsel; g += 1024) atomicAdd(&S.counts[sel[g]], 1u);
-    S.chist[threadIdx.x] = 0;
-    __syncthreads();
-    int which = 0;
-    for (int j = 1; j < ng; j++) if (S.counts[j] > S.counts[which]) which = j;      // indexOf(max): first
-    const uint32_t nsp = S.counts[which], m = nsp >> 1;
-    for (uint32_t g = threadIdx.x; g < nsel; g += 1024) if (sel[g] == which) atomicAdd(&S.chist[bcost[g] & 1023u], 1u);
-    __syncthreads();
-    {
-      const uint32_t hv = S.chist[threadIdx.x];
-      uint32_t tot;
-      const uint32_t cum = block_excl_sum<1024>(hv, S.sm, tot);
-      if (hv && cum <= m && m < cum + hv) { S.misc[0] = threadIdx.x; S.misc[1] = cum; }
-      __syncthreads();
-    }
-    const uint32_t cstar = S.misc[0], cumstar = S.misc[1];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nsel; base += 1024) {        // stable order inside the median cost bin (Q16)
-      const uint32_t g = base + threadIdx.x;
-      uint32_t f = 0, mine = 0xFFFFu;
-      if (g < nsel && sel[g] == which) { mine = bcost[g]; f = mine == cstar; }
-      uint32_t tot;
-      const uint32_t ex = block_excl_sum<1024>(f, S.sm, tot);
-      if (g < nsel && mine != 0xFFFFu) {
-        if (mine > cstar || (f && cumstar + carry + ex >= m)) sel[g] = (uint8_t)ng;
+  {
+    uint32_t* rep = stage + (threadIdx.x & 7u) * (6 * 260);
+    const uint4* A128 = reinterpret_cast<const uint4*>(A);                          // 8 symbols per load, two loads in flight
+    const uint32_t nv = (i_hi < npos ? i_hi : npos) / 8;
+    for (uint32_t v = i_lo / 8 + threadIdx.x; v < nv; v += 2048) {
+      const uint32_t v2 = v + 1024;
+      const uint4 x = A128[v];
+      const uint4 y = v2 < nv ? A128[v2] : make_uint4(0, 0, 0, 0);
+      const uint32_t i0 = v * 8, i1 = v2 * 8;
+      const uint32_t ga = i0 / GSZ, gb = (i0 + 7) / GSZ, gc = v2 < nv ? i1 / GSZ : 0u, gd = v2 < nv ? (i1 + 7) / GSZ : 0u;
+      const uint32_t sa = sel[ga], sb = sel[gb], sc = sel[gc], sd = sel[gd];
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t e0 = i0 + 2 * q, e1 = e0 + 1;
+        atomicAdd(&rep[(e0 / GSZ == ga ? sa : sb) * 260 + (xs[q] & 0xFFFFu)], 1u);
+        atomicAdd(&rep[(e1 / GSZ == ga ? sa : sb) * 260 + (xs[q] >> 16)], 1u);
       }
-      carry += tot;
-    }
-    if (ng == 2) HB_MARK(3);
-    ng++;
-    // MTF output is dominated by a few symbols: eight histogram replicas (by lane) in the idle staging buffer keep the
-    // same-address LDS atomics apart; they are summed afterwards
-    for (int i = threadIdx.x; i < 8 * 6 * 260; i += 1024) stage[i] = 0;
-    __syncthreads();
-    {                                                                               // Bzip2:2043-2048
-      uint32_t* rep = stage + (threadIdx.x & 7u) * (6 * 260);
-      const uint4* A128 = reinterpret_cast<const uint4*>(A);                          // 8 symbols per load, two loads in flight
-      const uint32_t nv = npos / 8;
-      for (uint32_t v = threadIdx.x; v < nv; v += 2048) {
-        const uint32_t v2 = v + 1024;
-        const uint4 x = A128[v];
-        const uint4 y = v2 < nv ? A128[v2] : make_uint4(0, 0, 0, 0);
-        const uint32_t i0 = v * 8, i1 = v2 * 8;
-        const uint32_t ga = i0 / GSZ, gb = (i0 + 7) / GSZ, gc = v2 < nv ? i1 / GSZ : 0u, gd = v2 < nv ? (i1 + 7) / GSZ : 0u;
-        const uint32_t sa = sel[ga], sb = sel[gb], sc = sel[gc], sd = sel[gd];
-        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+      if (v2 < nv) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const uint32_t e0 = i0 + 2 * q, e1 = e0 + 1;
-          atomicAdd(&rep[(e0 / GSZ == ga ? sa : sb) * 260 + (xs[q] & 0xFFFFu)], 1u);
-          atomicAdd(&rep[(e1 / GSZ == ga ? sa : sb) * 260 + (xs[q] >> 16)], 1u);
-        }
-        if (v2 < nv) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const uint32_t e0 = i1 + 2 * q, e1 = e0 + 1;
-            atomicAdd(&rep[(e0 / GSZ == gc ? sc : sd) * 260 + (ys[q] & 0xFFFFu)], 1u);
-            atomicAdd(&rep[(e1 / GSZ == gc ? sc : sd) * 260 + (ys[q] >> 16)], 1u);
-          }
+          const uint32_t e0 = i1 + 2 * q, e1 = e0 + 1;
+          atomicAdd(&rep[(e0 / GSZ == gc ? sc : sd) * 260 + (ys[q] & 0xFFFFu)], 1u);
+          atomicAdd(&rep[(e1 / GSZ == gc ? sc : sd) * 260 + (ys[q] >> 16)], 1u);
         }
       }
-      for (uint32_t i = nv * 8 + threadIdx.x; i < npos; i += 1024) atomicAdd(&rep[sel[i / GSZ] * 260 + A[i]], 1u);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 6 * 260; i += 1024) {
-      uint32_t f = 0;
-#pragma unroll
-      for (int r = 0; r < 8; r++) f += stage[r * (6 * 260) + i];
-      (&S.freq[0][0])[i] = f;
-    }
-    __syncthreads();
-    if (ng == 3) HB_MARK(4);
-    if (w < ng) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
-    __syncthreads();
-    if (ng == 3) HB_MARK(5);
+    if (i_hi >= npos) for (uint32_t i = nv * 8 + threadIdx.x; i < npos; i += 1024) atomicAdd(&rep[sel[i / GSZ] * 260 + A[i]], 1u);
   }
-  HB_MARK(6);
-  assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);                        // Bzip2:2163
-  __syncthreads();
+}
 
-  HB_MARK(7);
+// bit accounting of a block whose tables (S.lens) and selectors are final: tile offsets of the symbol data, selector MTF
+// positions, table bits, used-map bits, canonical codes, the block's bit length
+__device__ void block_accounting(HuffShared& S, HuffBufs& hb, uint32_t blk, const uint8_t* __restrict__ sel, uint8_t* __restrict__ selj,
+                                 const uint16_t* __restrict__ bcost, const uint8_t* __restrict__ alist_all, uint32_t nsel, uint32_t asz, int n, int ng) {
   // ---- bit accounting
   // data bits, and the bit offset of every 80-group tile inside the data (the tiles are packed in parallel)
   uint32_t data_bits = 0;
@@ -343,7 +414,6 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
     }
   }
   sel_bits = block_sum<1024>(sel_bits, S.sm);
-  HB_MARK(8);
   uint32_t tab_bits = 0;
   for (int i = threadIdx.x; i < ng * n; i += 1024) {                                // Bzip2:1926-1947
     const int t = i / n, s = i - t * n;
@@ -379,12 +449,151 @@ __global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* 
     gcodes[t * MAXSYM + s] = ((const uint32_t*)&S.work[0][0])[t * 32 + l] + r;
     glens[t * MAXSYM + s] = (uint8_t)l;
   }
-  HB_MARK(9);
   if (threadIdx.x == 0) {
     hb.ngroups[blk] = (uint32_t)ng;
     hb.bitlen[blk] = 80u + 25u + 16u + 16u * nranges + 18u + sel_bits + tab_bits + data_bits;
     hb.databits[blk] = data_bits;
   }
+}
+
+__global__ __launch_bounds__(1024) void huff_block(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride,
+                                                   const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
+                                                   const uint32_t* __restrict__ freq_all, const uint8_t* __restrict__ alist_all, int dbg) {
+  __shared__ HuffShared S;
+  __shared__ uint32_t stage[AS_GROUPS * 25];
+  const uint32_t blk = blockIdx.x;
+  const uint32_t npos = npos_all[blk], asz = asz_all[blk];
+  const int n = (int)asz + 2;
+  const uint16_t* A = Aall + (size_t)blk * a_stride;
+  uint8_t* sel = hb.sel + (size_t)blk * hb.sel_stride;
+  uint8_t* selj = hb.selj + (size_t)blk * hb.sel_stride;
+  uint16_t* bcost = hb.bcost + (size_t)blk * hb.sel_stride;
+  const uint32_t nsel = (npos + GSZ - 1) / GSZ;
+  const int target = npos >= 2400 ? 6 : npos >= 1200 ? 5 : npos >= 600 ? 4 : npos >= 200 ? 3 : 2;   // Bzip2:2150
+  const int w = wave_id();
+
+  HB_MARK(0);
+  // initial tables: global frequencies and flat (Bzip2:2155-2157)
+  for (int i = threadIdx.x; i < n; i += 1024) { S.freq[0][i] = freq_all[(size_t)blk * 258 + i]; S.freq[1][i] = 1; }
+  __syncthreads();
+  if (w < 2) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
+  __syncthreads();
+  int ng = 2;
+  HB_MARK(1);
+  while (ng < target) {                                                             // Bzip2:2012-2053
+    assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);
+    if (ng == 2) HB_MARK(2);
+    median_split(S, sel, bcost, nsel, ng);
+    if (ng == 2) HB_MARK(3);
+    ng++;
+    count_symbols(stage, A, sel, npos, 0u, npos);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 6 * 260; i += 1024) {
+      uint32_t f = 0;
+#pragma unroll
+      for (int r = 0; r < 8; r++) f += stage[r * (6 * 260) + i];
+      (&S.freq[0][0])[i] = f;
+    }
+    __syncthreads();
+    if (ng == 3) HB_MARK(4);
+    if (w < ng) build_table_wave(S.freq[w], S.lens[w], S.key[w], S.work[w], n);
+    __syncthreads();
+    if (ng == 3) HB_MARK(5);
+  }
+  HB_MARK(6);
+  assign_selectors(S, stage, A, npos, nsel, ng, sel, bcost);                        // Bzip2:2163
+  __syncthreads();
+
+  HB_MARK(7);
+  block_accounting(S, hb, blk, sel, selj, bcost, alist_all, nsel, asz, n, ng);
+  HB_MARK(8);
+  HB_MARK(9);
+}
+
+// ------------------------------------------------------------------ the same refinement as a chain of kernels
+// huff_block keeps one CU per block busy for ~0.9 ms while the other CUs idle (a -9 call of 100 MB has 112 blocks).  Its
+// per-group and per-symbol phases (selector assignment, symbol counts) are data-parallel, so here they are kernels of
+// their own with many workgroups per block; the per-block phases (median split, table builds, accounting) stay one
+// workgroup per block.  State between the kernels: code lengths wl[blk][6][264], counts wfreq[blk][6][260].
+// ng = tables in use when the kernel runs; a block takes part while ng <= / < its target (Bzip2:2150).
+__device__ __forceinline__ int huff_target(uint32_t npos) { return npos >= 2400 ? 6 : npos >= 1200 ? 5 : npos >= 600 ? 4 : npos >= 200 ? 3 : 2; }
+__device__ __forceinline__ void load_lens(HuffShared& S, const uint8_t* __restrict__ wl, int ng) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(wl);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&S.lens[0][0]);
+  for (int i = threadIdx.x; i < ng * 66; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+}
+__global__ __launch_bounds__(128) void hs_init(HuffBufs hb, const uint32_t* __restrict__ asz_all, const uint32_t* __restrict__ freq_all) {
+  __shared__ uint32_t freq[2][260], key[2][260];
+  __shared__ int work[2][260];
+  __shared__ uint8_t lens[2][264];
+  const uint32_t blk = blockIdx.x;
+  const int n = (int)asz_all[blk] + 2, w = wave_id();
+  for (int i = threadIdx.x; i < n; i += 128) { freq[0][i] = freq_all[(size_t)blk * 258 + i]; freq[1][i] = 1; }
+  __syncthreads();
+  build_table_wave(freq[w], lens[w], key[w], work[w], n);
+  __syncthreads();
+  uint8_t* wl = hb.wl + (size_t)blk * 6 * 264;
+  for (int i = threadIdx.x; i < 2 * 264; i += 128) wl[i] = (&lens[0][0])[i];
+}
+constexpr uint32_t HS_STEPS = 2;       // 512-group steps per workgroup of hs_assign
+__global__ __launch_bounds__(1024) void hs_assign(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride, const uint32_t* __restrict__ npos_all, int ng) {
+  __shared__ HuffShared S;
+  __shared__ uint32_t stage[AS_GROUPS * 25];
+  const uint32_t blk = blockIdx.y, npos = npos_all[blk], nsel = (npos + GSZ - 1) / GSZ;
+  const uint32_t g_lo = blockIdx.x * (HS_STEPS * AS_GROUPS);
+  if (ng > huff_target(npos) || g_lo >= nsel) return;
+  load_lens(S, hb.wl + (size_t)blk * 6 * 264, ng);
+  assign_selectors(S, stage, Aall + (size_t)blk * a_stride, npos, nsel, ng, hb.sel + (size_t)blk * hb.sel_stride, hb.bcost + (size_t)blk * hb.sel_stride,
+                   g_lo, g_lo + HS_STEPS * AS_GROUPS);
+}
+__global__ __launch_bounds__(1024) void hs_split(HuffBufs hb, const uint32_t* __restrict__ npos_all, int ng) {
+  __shared__ HuffShared S;
+  const uint32_t blk = blockIdx.x, npos = npos_all[blk], nsel = (npos + GSZ - 1) / GSZ;
+  if (ng >= huff_target(npos)) return;
+  median_split(S, hb.sel + (size_t)blk * hb.sel_stride, hb.bcost + (size_t)blk * hb.sel_stride, nsel, ng);
+  uint32_t* wf = hb.wfreq + (size_t)blk * 6 * 260;
+  for (int i = threadIdx.x; i < 6 * 260; i += 1024) wf[i] = 0;
+}
+constexpr uint32_t HS_CNT = 32768;     // symbols per workgroup of hs_count
+__global__ __launch_bounds__(1024) void hs_count(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride, const uint32_t* __restrict__ npos_all, int ng) {
+  __shared__ uint32_t stage[8 * 6 * 260];
+  const uint32_t blk = blockIdx.y, npos = npos_all[blk];
+  const uint32_t i_lo = blockIdx.x * HS_CNT;
+  if (ng >= huff_target(npos) || i_lo >= npos) return;
+  count_symbols(stage, Aall + (size_t)blk * a_stride, hb.sel + (size_t)blk * hb.sel_stride, npos, i_lo, i_lo + HS_CNT);
+  __syncthreads();
+  uint32_t* wf = hb.wfreq + (size_t)blk * 6 * 260;
+  for (int i = threadIdx.x; i < 6 * 260; i += 1024) {
+    uint32_t f = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) f += stage[r * (6 * 260) + i];
+    if (f) atomicAdd(&wf[i], f);
+  }
+}
+__global__ __launch_bounds__(384) void hs_build(HuffBufs hb, const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all, int ng /* before the new table */) {
+  __shared__ uint32_t freq[6][260], key[6][260];
+  __shared__ int work[6][260];
+  __shared__ uint8_t lens[6][264];
+  const uint32_t blk = blockIdx.x, npos = npos_all[blk];
+  if (ng >= huff_target(npos)) return;
+  const int n = (int)asz_all[blk] + 2, w = wave_id();
+  const uint32_t* wf = hb.wfreq + (size_t)blk * 6 * 260;
+  for (int i = threadIdx.x; i < 6 * 260; i += 384) (&freq[0][0])[i] = wf[i];
+  __syncthreads();
+  if (w <= ng) build_table_wave(freq[w], lens[w], key[w], work[w], n);
+  __syncthreads();
+  uint8_t* wl = hb.wl + (size_t)blk * 6 * 264;
+  for (int i = threadIdx.x; i < (ng + 1) * 264; i += 384) wl[i] = (&lens[0][0])[i];
+}
+__global__ __launch_bounds__(1024) void hs_finish(HuffBufs hb, const uint32_t* __restrict__ npos_all, const uint32_t* __restrict__ asz_all,
+                                                  const uint8_t* __restrict__ alist_all) {
+  __shared__ HuffShared S;
+  const uint32_t blk = blockIdx.x, npos = npos_all[blk], asz = asz_all[blk], nsel = (npos + GSZ - 1) / GSZ;
+  const int ng = huff_target(npos);
+  load_lens(S, hb.wl + (size_t)blk * 6 * 264, ng);
+  block_accounting(S, hb, blk, hb.sel + (size_t)blk * hb.sel_stride, hb.selj + (size_t)blk * hb.sel_stride, hb.bcost + (size_t)blk * hb.sel_stride,
+                   alist_all, nsel, asz, (int)asz + 2, ng);
 }
 
 // ------------------------------------------------------------------ bit offsets + stream CRC (one lane, tiny)
@@ -579,6 +788,7 @@ size_t HuffWork::bytes_needed(size_t max_blocks, uint32_t stride) {
   add(max_blocks * 6 * MAXSYM); add(max_blocks * 6 * MAXSYM * 4);
   add(max_blocks * 4); add(max_blocks * 4); add((max_blocks + 1) * 8); add(64);
   add(max_blocks * 4); add(max_blocks * (ss / PD_GROUPS + 2) * 4);
+  add(max_blocks * 6 * 264); add(max_blocks * 6 * 260 * 4);
   return b + 4096;
 }
 int HuffWork::carve(Arena& a, size_t max_blocks_, uint32_t stride) {
@@ -591,13 +801,34 @@ int HuffWork::carve(Arena& a, size_t max_blocks_, uint32_t stride) {
   scalars = a.take<uint64_t>(8);
   b.tile_stride = b.sel_stride / PD_GROUPS + 2;
   b.databits = a.take<uint32_t>(max_blocks); b.tileoff = a.take<uint32_t>(max_blocks * b.tile_stride);
-  return (scalars && b.tileoff) ? 0 : CJS_E_OUT_OF_MEMORY;
+  b.wl = a.take<uint8_t>(max_blocks * 6 * 264); b.wfreq = a.take<uint32_t>(max_blocks * 6 * 260);
+  max_stride = stride;
+  return (scalars && b.tileoff && b.wl && b.wfreq) ? 0 : CJS_E_OUT_OF_MEMORY;
 }
 
 int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                     const uint32_t* d_asz, const uint32_t* d_freq, const uint8_t* d_alist) {
   if (nb == 0) return 0;
   static const bool dbg = getenv("CJS_DEBUG") != nullptr;
+  // one workgroup per block (huff_block) keeps nb CUs busy; with fewer blocks than CUs the chain of kernels spreads the
+  // data-parallel phases over the whole chip (CJS_HUFF_SPLIT=0 / 1 forces one form)
+  static const int env_split = getenv("CJS_HUFF_SPLIT") ? atoi(getenv("CJS_HUFF_SPLIT")) : -1;
+  const bool split = env_split >= 0 ? env_split != 0 : (nb >= 8 && nb <= 512 && (size_t)nb * w.max_stride >= ((size_t)8 << 20));
+  if (split) {
+    const uint32_t max_sel = (uint32_t)(((size_t)w.max_stride + 1 + GSZ - 1) / GSZ);
+    const uint32_t ga = (max_sel + HS_STEPS * AS_GROUPS - 1) / (HS_STEPS * AS_GROUPS), gc = (w.max_stride + 1 + HS_CNT - 1) / HS_CNT;
+    hipLaunchKernelGGL(hs_init, dim3(nb), dim3(128), 0, s, w.b, d_asz, d_freq);
+    for (int ng = 2; ng <= 6; ng++) {
+      hipLaunchKernelGGL(hs_assign, dim3(ga, nb), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, ng);
+      if (ng == 6) break;
+      hipLaunchKernelGGL(hs_split, dim3(nb), dim3(1024), 0, s, w.b, d_npos, ng);
+      hipLaunchKernelGGL(hs_count, dim3(gc, nb), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, ng);
+      hipLaunchKernelGGL(hs_build, dim3(nb), dim3(384), 0, s, w.b, d_npos, d_asz, ng);
+    }
+    hipLaunchKernelGGL(hs_finish, dim3(nb), dim3(1024), 0, s, w.b, d_npos, d_asz, d_alist);
+    CJS_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(huff_block, dim3(nb), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_asz, d_freq, d_alist, dbg ? 1 : 0);
   CJS_HIP_TRY(hipGetLastError());
   if (dbg) {
@@ -605,8 +836,8 @@ int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A
     CJS_HIP_TRY(hipStreamSynchronize(s));
     CJS_HIP_TRY(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_huff_clk), sizeof clk));
     static const char* names[] = {"init tables", "assign(ng=2)", "median split(ng=2)", "freq count(ng=2->3)", "build tables(ng=3)",
-                                  "rest of refinement", "final assign", "bit accounting: data+selector mtf", "tables+codes"};
-    for (int i = 0; i < 9; i++) fprintf(stderr, "[cjs huff] wg0 %-36s %8.1f us\n", names[i], (double)(clk[i + 1] - clk[i]) / 100.0);
+                                  "rest of refinement", "final assign", "bit accounting, codes"};
+    for (int i = 0; i < 8; i++) fprintf(stderr, "[cjs huff] wg0 %-36s %8.1f us\n", names[i], (double)(clk[i + 1] - clk[i]) / 100.0);
   }
   return 0;
 }

@@ -16,7 +16,14 @@
 
 namespace cjs {
 
-constexpr int MTF_CHUNK = 512;
+#ifndef CJS_MTF_CHUNK
+#define CJS_MTF_CHUNK 512
+#endif
+#ifndef CJS_MTF_CL_THREADS
+#define CJS_MTF_CL_THREADS 256      /* ms_mtf 1.50 with 1024, 1.44 with 512, 1.40 with 256 (100 MB text, 512-head chunks; 256-head chunks: 1.46-1.56) */
+#endif
+constexpr int MTF_CHUNK = CJS_MTF_CHUNK;
+constexpr int MTF_CL_THREADS = CJS_MTF_CL_THREADS;      // workgroup size of mtf_chunk_lists (a multiple of 256)
 
 // ---- A: used-symbol list + run-head compaction.  Tiles of 4096 bytes: count -> per-block scan -> write.
 // tcnt[blk * tpb + tile] and the used flags (uflag[blk * 258 + byte], zeroed by the host) alias buffers that
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void mtf_seg_scan(MtfBufs mb) {
     if (l >= 0) key = 256 + l;
   }
 }
-__global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
+__global__ __launch_bounds__(MTF_CL_THREADS) void mtf_chunk_lists(MtfBufs mb) {
   __shared__ int keys[256];            // sort key of the u-th USED symbol (text uses ~100 of the 256 byte values: the
   __shared__ uint8_t symof[256];       // rank-by-counting is quadratic in the number of symbols that take part)
   __shared__ uint8_t uof[256];         // byte value -> used index
@@ -139,8 +146,9 @@ __global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
     keys[threadIdx.x] = mb.segkeys[((size_t)blk * mb.seg_stride + seg) * 256 + sym];
   }
   __syncthreads();
-  const uint32_t d = threadIdx.x & 255u, q = threadIdx.x >> 8, per = (nu + 3u) / 4u;
-  const uint32_t j0 = q * per, j1 = j0 + per < nu ? j0 + per : nu;
+  constexpr uint32_t NQ = MTF_CL_THREADS / 256;
+  const uint32_t d = threadIdx.x & 255u, q = threadIdx.x >> 8, per = (nu + NQ - 1u) / NQ;
+  const uint32_t j0 = q * per < nu ? q * per : nu, j1 = j0 + per < nu ? j0 + per : nu;
   for (uint32_t c = c0; c < c1; c++) {
     if (d < nu) {
       const int kd = keys[d];
@@ -150,12 +158,14 @@ __global__ __launch_bounds__(1024) void mtf_chunk_lists(MtfBufs mb) {
     }
     __syncthreads();
     if (threadIdx.x < nu) {
-      const uint32_t p = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+      uint32_t p = 0;
+#pragma unroll
+      for (uint32_t qq = 0; qq < NQ; qq++) p += part[qq][d];
       lists[(size_t)c * 256 + p] = symof[d];
     }
     __syncthreads();
-    if (threadIdx.x < MTF_CHUNK) {
-      const uint32_t h = c * MTF_CHUNK + threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < MTF_CHUNK; i += MTF_CL_THREADS) {
+      const uint32_t h = c * MTF_CHUNK + i;
       if (h < H) atomicMax(&keys[uof[hsym[h]]], (int)(256 + h));
     }
     __syncthreads();
@@ -345,7 +355,7 @@ int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const ui
   const uint32_t max_segs = (max_chunks + MTF_SEG - 1) / MTF_SEG;
   hipLaunchKernelGGL(mtf_seg_last, dim3(max_segs, nb), dim3(256), 0, s, w.b);
   hipLaunchKernelGGL(mtf_seg_scan, dim3(nb), dim3(256), 0, s, w.b);
-  hipLaunchKernelGGL(mtf_chunk_lists, dim3(max_segs, nb), dim3(1024), 0, s, w.b);
+  hipLaunchKernelGGL(mtf_chunk_lists, dim3(max_segs, nb), dim3(MTF_CL_THREADS), 0, s, w.b);
   hipLaunchKernelGGL(mtf_replay, dim3((max_chunks + 255) / 256, nb), dim3(256), 0, s, w.stride, w.b);
   dev_fill(s, w.b.freq, 0, (size_t)nb * 258 * 4);
   hipLaunchKernelGGL(mtf_emit_tiles<false>, dim3(tpb, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpb);
