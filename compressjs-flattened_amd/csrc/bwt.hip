@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ kin, con
     for (int s = 0; s < 16; s++) {
       const uint32_t loc = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
       const bool ok = loc < nvalid;
-      k[s] = ok ? kin[base + loc] : (K)~(K)0;
+      k[s] = ok ? kin[base + loc] : (K)~(K)0;           // (non-temporal loads here: no change, 12.69 vs 12.69 ms per step)
       v[s] = (ok && !NOVAL) ? vin[base + loc] : 0u;
     }
   }
@@ -405,9 +405,11 @@ __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint3
 }
 
 // per 4096-tile: #surviving elements, #surviving group heads, (last new-head index)+1
-__global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ key, uint32_t A, uint32_t* __restrict__ tile_cnt, uint32_t T, int gshift) {
+__global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ key, uint32_t A, uint32_t* __restrict__ tile_cnt, uint32_t T, int gshift,
+                                                 uint32_t* __restrict__ big_flag) {
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint32_t sm[4];
+  __shared__ uint32_t hword[64];          // per 64-slot word: holds a new group head
   const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
   uint32_t surv = 0, heads = 0, last = 0;
@@ -436,6 +438,16 @@ __global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ ke
       heads += nh && !single;
       if (nh) last = (uint32_t)a + 1u;
     }
+    const uint64_t hb = __ballot(loc < nvalid && (base + loc == 0 || sk[loc] != k[it]));
+    if (lane_id() == 0) hword[it * 4 + wave_id()] = hb != 0;
+  }
+  __syncthreads();
+  // a group of more than 1023 slots covers a whole aligned run of 512 slots: when every such run holds a head, no group is too
+  // large for the tile sorters of the next round (the host then skips their deferral bookkeeping)
+  if (threadIdx.x < 8 && base + (threadIdx.x + 1u) * 512u <= A) {
+    uint32_t any = 0;
+    for (int j = 0; j < 8; j++) any |= hword[threadIdx.x * 8 + j];
+    if (!any) atomicOr(big_flag, 1u);
   }
   surv = block_sum<256>(surv, sm);
   heads = block_sum<256>(heads, sm);
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ ti
     }
     c0 += t0; c1 += t1; cm = chunk_max > cm ? chunk_max : cm;
   }
-  if (threadIdx.x == 0) { counters[0] = c0; counters[1] = c1; host_mirror[0] = c0; host_mirror[1] = c1; }
+  if (threadIdx.x == 0) { counters[0] = c0; counters[1] = c1; host_mirror[0] = c0; host_mirror[1] = c1; host_mirror[4] = counters[4]; counters[4] = 0; }      // [4]: a group may exceed 1023 slots (bwt_flags / sweep 1)
 }
 
 // Wave-uniform: global index of the first slot of the class (key >> shift) that runs into slot `base` from the left, inside
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
                                                  uint32_t* tile_cnt, uint32_t T,
                                                  uint32_t* __restrict__ R, uint32_t* __restrict__ SA,
                                                  uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord, HalfMap hm_,
-                                                 const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U) {
+                                                 const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U, uint32_t* __restrict__ big_flag) {
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
@@ -592,6 +604,13 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
     wp_s[lane] = is - sv; wp_h[lane] = ih - hd; wp_head[lane] = em;
     if (SWEEP == 1 && lane == 63) {          // what bwt_flags counts: survivors, surviving heads, (last head index) + 1
       tile_cnt[tile] = is; tile_cnt[T + tile] = ih; tile_cnt[2 * (size_t)T + tile] = im ? (uint32_t)base + im : 0u;
+    }
+    if (SWEEP == 1) {                        // (and its test for groups of more than 1023 slots: an aligned run of 512 slots without a head)
+      const uint64_t nz = __ballot(mh != 0);
+      bool bad = false;
+#pragma unroll
+      for (int b = 0; b < 8; b++) bad |= base + (uint64_t)(b + 1) * 512u <= A && ((nz >> (8 * b)) & 0xFFull) == 0;
+      if (bad && lane == 0) atomicOr(big_flag, 1u);
     }
   }
   __syncthreads();
@@ -1084,31 +1103,64 @@ __global__ __launch_bounds__(1024) void scan_u32_single(uint32_t* __restrict__ a
   }
   if (threadIdx.x == 0) { *total = carry; *host_total = carry; }
 }
-__global__ __launch_bounds__(256) void bwt_defer_count(uint32_t A, const uint8_t* __restrict__ dflag, uint32_t* __restrict__ tcount) {
+// Groups too large for the tile sorters (dflag = 1 on all their slots) are compacted, sorted by the global radix passes and
+// put back.  Their group ordinals take ~23 bits of the sort key; numbered densely among themselves (there are at most
+// A / 1025 of them) they take ~11, which saves two of the six passes: a slot starts a deferred group when the slot in front of
+// it is not deferred or carries another ordinal.  Per 2048-slot tile: deferred slots -> tcount, deferred group heads -> hcount.
+__device__ __forceinline__ void defer_flags(uint32_t A, const uint8_t* __restrict__ dflag, const uint64_t* __restrict__ key, uint64_t a0,
+                                            uint32_t& f, uint32_t& heads, uint64_t (&k8)[8]) {
+  f = 0; heads = 0;
+  if (a0 >= A) return;
+  if (a0 + 8 <= A) {
+    const uint64_t w = *(const uint64_t*)(dflag + a0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) f |= (uint32_t)((w >> (8 * j)) & 1ull) << j;
+  } else for (int j = 0; j < 8; j++) if (a0 + j < A && dflag[a0 + j]) f |= 1u << j;
+  if (!f) return;
+#pragma unroll
+  for (int j = 0; j < 8; j++) k8[j] = a0 + j < A ? key[a0 + j] : 0ull;
+  const bool pf = a0 && dflag[a0 - 1];
+  uint64_t prev = pf ? key[a0 - 1] >> 20 : ~0ull;
+  bool prev_def = pf;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const bool d = (f >> j) & 1u;
+    if (d && (!prev_def || prev != (k8[j] >> 20))) heads |= 1u << j;
+    prev_def = d; prev = k8[j] >> 20;
+  }
+}
+__global__ __launch_bounds__(256) void bwt_defer_count(uint32_t A, const uint8_t* __restrict__ dflag, const uint64_t* __restrict__ key,
+                                                       uint32_t* __restrict__ tcount, uint32_t* __restrict__ hcount) {
   __shared__ uint32_t sm[4];
   const uint64_t a0 = (uint64_t)blockIdx.x * TS_GT + (uint32_t)threadIdx.x * 8u;
-  uint32_t cnt = 0;
-  if (a0 + 8 <= A) { const uint64_t f = *(const uint64_t*)(dflag + a0); cnt = (uint32_t)__builtin_popcountll(f & 0x0101010101010101ull); }
-  else for (int j = 0; j < 8; j++) if (a0 + j < A && dflag[a0 + j]) cnt++;
-  cnt = block_sum<256>(cnt, sm);
-  if (threadIdx.x == 0) tcount[blockIdx.x] = cnt;
+  uint32_t f, heads; uint64_t k8[8];
+  defer_flags(A, dflag, key, a0, f, heads, k8);
+  const uint32_t cnt = block_sum<256>((uint32_t)__builtin_popcount(f), sm);
+  const uint32_t hc = block_sum<256>((uint32_t)__builtin_popcount(heads), sm);
+  if (threadIdx.x == 0) { tcount[blockIdx.x] = cnt; hcount[blockIdx.x] = hc; }
 }
 __global__ __launch_bounds__(256) void bwt_defer_gather(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t A,
-                                                        const uint8_t* __restrict__ dflag, const uint32_t* __restrict__ tcount,
+                                                        const uint8_t* __restrict__ dflag, const uint32_t* __restrict__ tcount, const uint32_t* __restrict__ hcount,
                                                         uint64_t* __restrict__ dk, uint32_t* __restrict__ dv, uint32_t* __restrict__ dpos) {
   __shared__ uint32_t sm[4];
   const uint64_t a0 = (uint64_t)blockIdx.x * TS_GT + (uint32_t)threadIdx.x * 8u;
-  uint32_t f = 0, cnt = 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) if (a0 + j < A && dflag[a0 + j]) { f |= 1u << j; cnt++; }
+  uint32_t f, heads; uint64_t k8[8];
+  defer_flags(A, dflag, key, a0, f, heads, k8);
   uint32_t tot;
-  uint32_t o = tcount[blockIdx.x] + block_excl_sum<256>(cnt, sm, tot);
+  uint32_t o = tcount[blockIdx.x] + block_excl_sum<256>((uint32_t)__builtin_popcount(f), sm, tot);
+  uint32_t hid = hcount[blockIdx.x] + block_excl_sum<256>((uint32_t)__builtin_popcount(heads), sm, tot);      // deferred heads in front of this thread's slots
 #pragma unroll
-  for (int j = 0; j < 8; j++) if ((f >> j) & 1u) { dk[o] = key[a0 + j]; dv[o] = val[a0 + j]; dpos[o] = (uint32_t)(a0 + j); o++; }
+  for (int j = 0; j < 8; j++) if ((f >> j) & 1u) {
+    hid += (heads >> j) & 1u;
+    dk[o] = ((uint64_t)(hid - 1u) << 20) | (k8[j] & 0xFFFFFull); dv[o] = val[a0 + j]; dpos[o] = (uint32_t)(a0 + j); o++;
+  }
 }
 __global__ __launch_bounds__(256) void bwt_defer_scatter(uint32_t D, const uint64_t* __restrict__ dk, const uint32_t* __restrict__ dv,
                                                          const uint32_t* __restrict__ dpos, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
-  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < D; j += (uint64_t)gridDim.x * 256) { const uint32_t a = dpos[j]; key[a] = dk[j]; val[a] = dv[j]; }
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < D; j += (uint64_t)gridDim.x * 256) {
+    const uint32_t a = dpos[j];          // a slot of the same group: its ordinal stays, the rank key is the sorted one
+    key[a] = (key[a] & ~0xFFFFFull) | (dk[j] & 0xFFFFFull); val[a] = dv[j];
+  }
 }
 
 __global__ __launch_bounds__(256) void bwt_flush_active(uint32_t A, const uint32_t* __restrict__ val, const uint32_t* __restrict__ pos,
@@ -1413,7 +1465,9 @@ static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int
   }
   dev_fill(s, dflag, 1, A);
   launch_tile_sort(s, Tt, w.key[c], w.val[c], A, dflag, ngroups, tg);
-  hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, tcount);
+  uint32_t* hcount = w.hist;                            // (free until the radix passes below, which come after the last reader of hcount)
+  hipLaunchKernelGGL(bwt_defer_count, dim3(Tg), dim3(256), 0, s, A, dflag, w.key[c], tcount, hcount);
+  hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, hcount, Tg, w.counters + 3, w.h_counters + 3);      // deferred groups
   hipLaunchKernelGGL(scan_u32_single, dim3(1), dim3(1024), 0, s, tcount, Tg, w.counters + 2, w.h_counters + 2);      // the kernel writes the pinned mirror itself
   CJS_HIP_TRY(hipStreamSynchronize(s));
   const uint32_t D = w.h_counters[2];
@@ -1424,9 +1478,10 @@ static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int
   uint64_t* dk0 = w.key[1 - c]; uint64_t* dk1 = dk0 + w.cap / 2;
   uint32_t* dv0 = w.val[1 - c]; uint32_t* dv1 = dv0 + w.cap / 2;
   uint32_t* dpos = w.pos[1 - pc];
-  hipLaunchKernelGGL(bwt_defer_gather, dim3(Tg), dim3(256), 0, s, w.key[c], w.val[c], A, dflag, tcount, dk0, dv0, dpos);
+  hipLaunchKernelGGL(bwt_defer_gather, dim3(Tg), dim3(256), 0, s, w.key[c], w.val[c], A, dflag, tcount, hcount, dk0, dv0, dpos);
   int cur = 0;
-  CJS_TRY((radix_passes<uint64_t>(s, w, dk0, dv0, dk1, dv1, cur, D, 0, bits, lt)));
+  const uint32_t ndg = w.h_counters[3];                 // deferred groups: dense ordinals 0 .. ndg-1 above the 20-bit rank key
+  CJS_TRY((radix_passes<uint64_t>(s, w, dk0, dv0, dk1, dv1, cur, D, 0, 20 + bits_for(ndg ? ndg - 1 : 0), lt)));
   hipLaunchKernelGGL(bwt_defer_scatter, dim3((D + 255) / 256 < 8192u ? (D + 255) / 256 : 8192u), dim3(256), 0, s, D, cur ? dk1 : dk0, cur ? dv1 : dv0, dpos,
                      w.key[c], w.val[c]);
   CJS_HIP_TRY(hipGetLastError());
@@ -1478,6 +1533,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   // two-sweep scheduling of the round-1 rank scatter (see HalfMap): pays only with the packed records (the second sweep of the
   // 12-byte key + value form re-reads more than the merged stores save: 2.15 vs 1.64 ms)
   const bool sweeps = env_halves >= 2 && nb >= 8 && packed;
+  static const bool env_big = getenv("CJS_BIG_GROUP_TEST") == nullptr || atoi(getenv("CJS_BIG_GROUP_TEST")) != 0;
   static const bool env_fuse = getenv("CJS_FUSE_GATHER") == nullptr || atoi(getenv("CJS_FUSE_GATHER")) != 0;
   bool fuse = false;
   TsGather tg{nullptr, nullptr, nullptr, 0u, 0, g};
@@ -1502,13 +1558,13 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     if (rounds == 0 && packed && sweeps && env_halves == 3) {          // two launches, no counting pass (see bwt_apply)
       const HalfMap hm{2u, 0u, stride};
       hipLaunchKernelGGL((bwt_apply<true, true, 1>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
       hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
       CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
       hipLaunchKernelGGL((bwt_apply<true, true, 2>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
     } else {
-    hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0);
+    hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0, w.counters + 4);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
     CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
     if (rounds == 0) {
@@ -1519,17 +1575,18 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
         grid = 8u * ((nb + 7u) / 8u) * 2u * hm.slots;
       }
       if (packed) hipLaunchKernelGGL((bwt_apply<true, true>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                                     w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
+                                     w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
       else hipLaunchKernelGGL((bwt_apply<true, false>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                              w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU);
+                              w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
     } else hipLaunchKernelGGL((bwt_apply<false, false>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride}, dT, dU);
+                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride}, dT, dU, w.counters + 4);
     }
     // the host only needs the counters of the tile scan: it waits for THAT kernel and queues the next round behind the regroup
     // kernel while it runs (a stream synchronisation here left the GPU idle for ~20 us per round)
     CJS_HIP_TRY(hipEventSynchronize(w.ev_scan));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
+    if (w.h_counters[4] == 0 && env_big) w.no_large_groups = true;       // every group of the new grouping fits the tile sorters
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt] round %u h=%u A=%u bits=%d -> A'=%u groups=%u\n", rounds, h, A, bits, A2, NG);
     c = 1 - c; pc = 1 - pc;
     A = A2; ngroups = NG;

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(128) void hs_init(HuffBufs hb, const uint32_t* __re
   uint8_t* wl = hb.wl + (size_t)blk * 6 * 264;
   for (int i = threadIdx.x; i < 2 * 264; i += 128) wl[i] = (&lens[0][0])[i];
 }
-constexpr uint32_t HS_STEPS = 2;       // 512-group steps per workgroup of hs_assign
+constexpr uint32_t HS_STEPS = 4;       // 512-group steps per workgroup of hs_assign
 __global__ __launch_bounds__(1024) void hs_assign(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride, const uint32_t* __restrict__ npos_all, int ng) {
   __shared__ HuffShared S;
   __shared__ uint32_t stage[AS_GROUPS * 25];
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(1024) void hs_split(HuffBufs hb, const uint32_t* __
   uint32_t* wf = hb.wfreq + (size_t)blk * 6 * 260;
   for (int i = threadIdx.x; i < 6 * 260; i += 1024) wf[i] = 0;
 }
-constexpr uint32_t HS_CNT = 32768;     // symbols per workgroup of hs_count
+constexpr uint32_t HS_CNT = 131072;     // symbols per workgroup of hs_count
 __global__ __launch_bounds__(1024) void hs_count(HuffBufs hb, const uint16_t* __restrict__ Aall, size_t a_stride, const uint32_t* __restrict__ npos_all, int ng) {
   __shared__ uint32_t stage[8 * 6 * 260];
   const uint32_t blk = blockIdx.y, npos = npos_all[blk];

@@ -337,13 +337,16 @@ def _run_variant(env, n, seed, level):
                                  {"CJS_TILE_SORT": "radix"}, {"CJS_TILE_SORT": "count"}, {"CJS_R1_TWO_PHASE": "1"}, {"CJS_R1_TWO_PHASE": "0"}, {"CJS_NO_TILE_SORT": "1"}, {"CJS_NO_SEGMENTED_SORT": "1"},
                                  {"CJS_APPLY_HALVES": "3"}, {"CJS_APPLY_HALVES": "2"},
                                  {"CJS_FUSE_GATHER": "0"}, {"CJS_FUSE_GATHER": "0", "CJS_TILE_SORT": "radix"}, {"CJS_FUSE_GATHER": "1", "CJS_TILE_SORT": "count"},
-                                 {"CJS_R1_PACKED": "1", "CJS_APPLY_HALVES": "2", "CJS_TILE_SORT": "radix"}],
+                                 {"CJS_R1_PACKED": "1", "CJS_APPLY_HALVES": "2", "CJS_TILE_SORT": "radix"},
+                                 {"CJS_DIRECT_EMIT": "0"}, {"CJS_R1_DIG": "0"}, {"CJS_HB_HR": "2"}, {"CJS_HB_HR": "8"}, {"CJS_BIG_GROUP_TEST": "0"},
+                                 {"CJS_HUFF_SPLIT": "1"}, {"CJS_HUFF_SPLIT": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_suffix_sort_variants_are_bit_exact(oracle, env):
-    # every A/B toggle of the suffix sorter (round-1 record format, two-sweep rank scatter, tile sorter flavour, fallbacks)
+    # every A/B toggle of the suffix sorter (round-1 record format, two-sweep rank scatter, tile sorter flavour, fallbacks, direct
+    # emit, digit bytes, large-group test) and the two forms of the Huffman refinement (one kernel per block / chain of kernels)
     # must give the same stream: 2.5 MB at level 9 (three blocks) and 1.2 MB at level 1 (13 blocks: the two-sweep path needs >= 8)
     cases = [(2500000, 4, 9), (1200000, 6, 1)]
-    if "CJS_APPLY_HALVES" in env:
+    if "CJS_APPLY_HALVES" in env or "CJS_HUFF_SPLIT" in env or "CJS_BIG_GROUP_TEST" in env:
         cases.append((7400000, 8, 9))        # nine level-9 blocks: the two-sweep gather / scatter of rounds >= 2 runs for several rounds
     for n, seed, level in cases:
         rc, want = oracle.bzip2_compress(recipes.textgen(n, seed), level)
