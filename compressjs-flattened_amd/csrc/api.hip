@@ -31,7 +31,7 @@ int cjs_device_count(void) {
   return n;
 }
 
-void cjs_free(void* p) { free(p); }
+void cjs_free(void* p) { cjs::HostPool::give(p); }
 
 const char* cjs_last_error_detail(void) { return g_detail; }
 
@@ -103,6 +103,63 @@ void DevPool::trim() {
     g_pool.erase(g_pool.begin() + (long)i);
   }
   if (have) (void)hipSetDevice(cur);
+}
+
+// ---- HostPool (see cjs_internal.h)
+namespace {
+struct HostBuf { void* p; size_t bytes; bool busy; };
+std::mutex g_host_mu;
+std::vector<HostBuf> g_host;
+size_t host_idle_limit() {
+  static const size_t mb = getenv("CJS_PINNED_RESULT_MB") ? (size_t)strtoull(getenv("CJS_PINNED_RESULT_MB"), nullptr, 10) : 2048;
+  return mb << 20;
+}
+}  // namespace
+void* HostPool::take(size_t bytes) {
+  if (!bytes) bytes = 1;
+  const size_t limit = host_idle_limit();
+  if (bytes < ((size_t)1 << 20) || !limit) return malloc(bytes);
+  {
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    HostBuf* best = nullptr;
+    for (auto& b : g_host) if (!b.busy && b.bytes >= bytes && b.bytes / 2 <= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) { best->busy = true; return best->p; }
+  }
+  void* p = nullptr;
+  const size_t cap = bytes + bytes / 16;                 // a later result of about the same size fits too
+  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) { (void)hipGetLastError(); return malloc(bytes); }
+  std::lock_guard<std::mutex> lock(g_host_mu);
+  g_host.push_back(HostBuf{p, cap, true});
+  return p;
+}
+void HostPool::give(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    for (size_t i = 0; i < g_host.size(); i++) if (g_host[i].p == p) {
+      g_host[i].busy = false;
+      size_t idle = 0;
+      for (auto& b : g_host) if (!b.busy) idle += b.bytes;
+      for (size_t j = 0; j < g_host.size() && idle > host_idle_limit();) {      // over the limit: the largest idle buffers go first
+        size_t big = g_host.size();
+        for (size_t k = 0; k < g_host.size(); k++) if (!g_host[k].busy && (big == g_host.size() || g_host[k].bytes > g_host[big].bytes)) big = k;
+        if (big == g_host.size()) break;
+        idle -= g_host[big].bytes;
+        (void)hipHostFree(g_host[big].p);
+        g_host.erase(g_host.begin() + (long)big);
+      }
+      return;
+    }
+  }
+  free(p);                                               // not pinned: plain malloc
+}
+void HostPool::trim() {
+  std::lock_guard<std::mutex> lock(g_host_mu);
+  for (size_t i = 0; i < g_host.size();) {
+    if (g_host[i].busy) { i++; continue; }
+    (void)hipHostFree(g_host[i].p);
+    g_host.erase(g_host.begin() + (long)i);
+  }
 }
 
 int select_device(const cjs_opts* opts) {

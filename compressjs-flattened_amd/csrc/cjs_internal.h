@@ -70,6 +70,16 @@ struct DevPool {
   static void give(void* p);
   static void trim();
 };
+// Result buffers handed to the caller by the host-buffer entry points ("malloc'd by the library; release with cjs_free").
+// Large results come from a cache of PINNED host buffers: the device-to-host copy of the result is then one DMA at link speed
+// into pages that exist already, instead of a staged copy into fresh pageable memory that faults page by page (100 MB:
+// ~20 ms).  cjs_free() returns such a buffer to the cache (at most CJS_PINNED_RESULT_MB of idle buffers are kept, default
+// 2048; 0 = results are plain malloc), cjs_trim() frees the idle ones.  Small results are plain malloc.
+struct HostPool {
+  static void* take(size_t bytes);      // never pinned below 1 MiB; falls back to malloc when pinning fails
+  static void give(void* p);            // any pointer take() returned (or malloc'd memory)
+  static void trim();
+};
 inline int Arena::init_pooled(size_t bytes) {
   base = (uint8_t*)DevPool::take(bytes);
   if (!base) return CJS_E_OUT_OF_MEMORY;

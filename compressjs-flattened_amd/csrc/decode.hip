@@ -1437,7 +1437,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   J.out_off.assign(nb + 1, 0);
   for (size_t k = 0; k < nb; k++) J.out_off[k + 1] = J.out_off[k] + J.chain[k].out_len;
   const uint64_t total = J.out_off[nb];
-  if (out && !pending_rc) { J.host = (uint8_t*)malloc(total ? (size_t)total : 1); if (!J.host) { release_all(); return CJS_E_OUT_OF_MEMORY; } }
+  if (out && !pending_rc) { J.host = (uint8_t*)HostPool::take(total ? (size_t)total : 1); if (!J.host) { release_all(); return CJS_E_OUT_OF_MEMORY; } }
   const auto T2 = std::chrono::steady_clock::now();
   rc = for_each_share(sh, &J, dec_phase_c);
   const double ms_c = ms_since(T2);
@@ -1447,7 +1447,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
     for (uint32_t i = 0; i < nsh; i++) fprintf(stderr, "[cjs dec]   share %u (device %d): %zu candidates, blocks [%zu, %zu): %.2f / %.2f / %.2f ms\n", i, sh[i].device,
                                                sh[i].cands.size(), sh[i].c0, sh[i].c1, sh[i].ms_a, sh[i].ms_b, sh[i].ms_c);
   }
-  if (rc) { free(J.host); return rc; }
+  if (rc) { HostPool::give(J.host); return rc; }
   if (pending_rc) { set_detail("%s", pending_detail); return pending_rc; }
   if (tab_n) {
     *tab_n = (long)nb;

@@ -380,12 +380,12 @@ extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_
   if (!rc) rc = cjs_bzip2_compress_device(c, hc.d_in, n, level, hc.d_out, out_cap, &len, st);
   const auto t3 = now();
   uint8_t* host = nullptr;
-  if (!rc) { host = (uint8_t*)malloc(len ? len : 1); if (!host) rc = CJS_E_OUT_OF_MEMORY; }
+  if (!rc) { host = (uint8_t*)HostPool::take(len ? len : 1); if (!host) rc = CJS_E_OUT_OF_MEMORY; }
   if (!rc && hipMemcpy(host, hc.d_out, len, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
   const auto t4 = now();
   if (dbg) fprintf(stderr, "[cjs] host compress: workspace %.2f ms, H2D %.2f ms, pipeline %.2f ms, malloc + D2H %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
   if (rc || no_cache) hc.release();           // after an error the cached state is not trusted
-  if (rc) { free(host); return rc; }
+  if (rc) { HostPool::give(host); return rc; }
   *out = host; *out_n = len;
   return 0;
   CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
@@ -393,6 +393,7 @@ extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_
 
 extern "C" void cjs_trim(void) {
   DevPool::trim();
+  HostPool::trim();
   int cur = 0;
   const bool have = hipGetDevice(&cur) == hipSuccess;
   for (int d = 0; d < MAX_CACHED_DEVICES; d++) {
