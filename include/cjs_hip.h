@@ -70,7 +70,8 @@ typedef struct cjs_opts {
  * cjs_bzip2_decompress replaces Bzip2.decompressFile  J/Bzip2_joined_.js:1769-1796
  * cjs_bwtc_compress    replaces BWTC.compressFile     J/BWTC_joined_.js:1698-1825
  * cjs_bwtc_decompress  replaces BWTC.decompressFile   J/BWTC_joined_.js:1827-1920
- * `*out` is malloc'd by the library; release with cjs_free.  level: 1..9 (bzip2: else
+ * `*out` is allocated by the library (plain malloc, or for results of 1 MiB and more a cached pinned host buffer: see
+ * cjs_trim); release it with cjs_free and with nothing else.  level: 1..9 (bzip2: else
  * CJS_E_BAD_LEVEL; bwtc: else 9, J/BWTC_joined_.js:1702-1705). */
 int cjs_bzip2_compress(const uint8_t *in, size_t n, int level, uint8_t **out, size_t *out_n, const cjs_opts *opts);
 int cjs_bzip2_decompress(const uint8_t *in, size_t n, int multistream, uint8_t **out, size_t *out_n, const cjs_opts *opts);
@@ -85,7 +86,9 @@ void cjs_free(void *p);
 /* Memory kept between calls (allocating and freeing multi-GB scratch costs more than compressing 100 MB):
  * cjs_bzip2_compress keeps its per-device workspace (~70 B per input byte of the largest call so far) and staging buffers;
  * cjs_bzip2_decompress / _table / _decompress_block keep their device scratch buffers (~25 B per output byte) in a
- * per-device pool.  cjs_trim() returns all of it to the driver; environment CJS_NO_CTX_CACHE=1: never keep anything. */
+ * per-device pool; result buffers given back with cjs_free stay pinned for the next result (at most CJS_PINNED_RESULT_MB
+ * megabytes of idle ones, default 2048; 0 = results are plain malloc).  cjs_trim() returns all of it to the driver;
+ * environment CJS_NO_CTX_CACHE=1: never keep device memory. */
 void cjs_trim(void);
 const char *cjs_strerror(int code);
 /* Detail text of the most recent FAILED call on the calling thread, "" if it had none: the reference's optDetail
