@@ -58,6 +58,11 @@ struct GenSrc { const uint8_t* T; int cyclic, nsym, packed; };
 // position in the block (bits 19..0): a radix pass moves 8 B per suffix each way instead of 12, and there is no value array
 constexpr int PK_SHIFT = 20, PK_KEY_LO = 24;
 constexpr uint32_t PK_POS_MASK = (1u << PK_SHIFT) - 1u;
+// records of the two-phase sort after bwt_phase2_records: byte0 . byte1 (63..48) | rank of the class of bytes 2..6 (47..28) | the byte IN
+// FRONT of the suffix (27..20) | position (19..0).  The group key is key >> PK2_GSHIFT; block boundaries are taken from the slot
+// number (no parity bit).  The byte in front is what the BWT emits for the suffix: it rides along (later in the top byte of val[])
+// so that the regroup kernels write BWT bytes without gathering them from the text.
+constexpr int PK2_GSHIFT = 28, PK2_PREV_SHIFT = 20, VAL_PREV_SHIFT = 24;
 constexpr uint32_t GEN_PAD = 8;
 // stages the tile's bytes (+GEN_PAD lookahead) in LDS; returns the byte offset of the tile's first byte inside tb (< 4):
 // tiles that do not touch the end of their block are copied as aligned 32-bit words from the aligned-down address
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint3
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const uint32_t blk = p16[it] / g.stride, n = blk_len(g, blk);
-    uint32_t j = v16[it] + h;                  // (both below 2^31)
+    uint32_t j = (v16[it] & PK_POS_MASK) + h;  // (both below 2^31; the top byte of val[] may carry the byte in front of the suffix)
     if (cyclic) { if (j >= n) j %= n; }
     const bool past = !cyclic && j >= n;
     kk[it] = R[(size_t)blk * g.stride + (past ? 0 : j)] + 1u;
@@ -406,13 +411,14 @@ __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint3
 
 // per 4096-tile: #surviving elements, #surviving group heads, (last new-head index)+1
 __global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ key, uint32_t A, uint32_t* __restrict__ tile_cnt, uint32_t T, int gshift,
-                                                 uint32_t* __restrict__ big_flag) {
+                                                 uint32_t* __restrict__ big_flag, uint32_t first_stride /* round 1: block stride (a block start is a head), else 0 */) {
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint32_t sm[4];
   __shared__ uint32_t hword[64];          // per 64-slot word: holds a new group head
   const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
   const uint32_t nvalid = (uint32_t)((uint64_t)A - base < RS_TILE ? (uint64_t)A - base : RS_TILE);
   uint32_t surv = 0, heads = 0, last = 0;
+  const uint64_t bnd = first_stride ? (base + first_stride - 1u) / first_stride * first_stride : ~0ull;      // the block start in [base, base + tile]
   // the tile's keys go through LDS so that every global load is issued up front (neighbours come from LDS, not from three
   // loads per element that the compiler waits for one by one)
   uint64_t k[16];
@@ -431,14 +437,14 @@ __global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ ke
     const uint32_t loc = (uint32_t)it * 256 + threadIdx.x;
     const uint64_t a = base + loc;
     if (loc < nvalid) {
-      const bool nh = a == 0 || sk[loc] != k[it];
-      const bool nx = a + 1 == A || sk[loc + 2] != k[it];
+      const bool nh = a == 0 || a == bnd || sk[loc] != k[it];
+      const bool nx = a + 1 == A || a + 1 == bnd || sk[loc + 2] != k[it];
       const bool single = nh && nx;
       surv += !single;
       heads += nh && !single;
       if (nh) last = (uint32_t)a + 1u;
     }
-    const uint64_t hb = __ballot(loc < nvalid && (base + loc == 0 || sk[loc] != k[it]));
+    const uint64_t hb = __ballot(loc < nvalid && (base + loc == 0 || base + loc == bnd || sk[loc] != k[it]));
     if (lane_id() == 0) hword[it * 4 + wave_id()] = hb != 0;
   }
   __syncthreads();
@@ -528,7 +534,8 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
                                                  uint32_t* tile_cnt, uint32_t T,
                                                  uint32_t* __restrict__ R, uint32_t* __restrict__ SA,
                                                  uint32_t* __restrict__ nval, uint32_t* __restrict__ npos, uint32_t* __restrict__ ngord, HalfMap hm_,
-                                                 const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U, uint32_t* __restrict__ big_flag) {
+                                                 const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U, uint32_t* __restrict__ big_flag,
+                                                 int gs1 /* FIRST: group key = key >> gs1 */, int carried /* the byte in front of a suffix rides in its record / val */) {
   __shared__ uint64_t sk[RS_TILE + 2];
   __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   if (SWEEP != 1) { sbase = tile_cnt[tile]; hbase = tile_cnt[T + tile]; carry = tile_cnt[2 * (size_t)T + tile]; }
   else if (w == 0) {
     const uint64_t seg0 = (uint64_t)((uint32_t)base / g.stride) * g.stride;     // (round 1: slot = sorted position)
-    const uint32_t c = (uint32_t)class_head_before(key, seg0, base, PACKED ? PK_SHIFT : 0, lane) + 1u;
+    const uint32_t c = (uint32_t)class_head_before(key, seg0, base, gs1, lane) + 1u;
     if (lane == 0) carry_s = c;
   }
   uint32_t p16[FIRST ? 1 : 16], v16[PACKED ? 1 : 16];
@@ -573,15 +580,16 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
     }
   }
   __syncthreads();
-  constexpr int GS = PACKED ? PK_SHIFT : 0;      // packed records: the group key sits above the position bits
+  const int GS = FIRST ? gs1 : 0;                // packed records: the group key sits above the position (and carried byte) bits
+  const uint64_t bnd = FIRST ? (base + g.stride - 1u) / g.stride * g.stride : ~0ull;      // round 1: a block start is a head (slot = sorted position)
 #pragma unroll 4
   for (int it = 0; it < 16; it++) {
     const uint32_t e = (uint32_t)it * 256u + tid;
     const uint64_t a = base + e;
     const bool ok = e < nvalid;
     const uint64_t k = sk[e + 1] >> GS;
-    const bool nh = ok && (a == 0 || (sk[e] >> GS) != k);
-    const bool nx = a + 1 == A || (sk[e + 2] >> GS) != k;
+    const bool nh = ok && (a == 0 || a == bnd || (sk[e] >> GS) != k);
+    const bool nx = a + 1 == A || a + 1 == bnd || (sk[e + 2] >> GS) != k;
     const uint64_t mnh = __ballot(nh), msg = __ballot(nh && nx);
     if (lane == 0) { m_nh[it * 4 + w] = mnh; m_sg[it * 4 + w] = msg; }
     if (!FIRST) {
@@ -618,14 +626,16 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   const uint64_t lt = (1ull << lane) - 1ull, le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
   // BWT bytes of the suffixes this tile resolves (see the store below): all sixteen gathers are issued before the loop
   uint32_t ub[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) ub[it] = 0u;
   const bool emits = U != nullptr && !(SWEEP == 0 ? half != 0 : SWEEP == 1);
-  if (emits) {
+  if (emits && !carried) {
 #pragma unroll
     for (int it = 0; it < 16; it++) {
       const uint32_t e = (uint32_t)it * 256u + tid;
       const bool sing = e < nvalid && ((m_sg[it * 4 + w] >> lane) & 1ull);
       const uint32_t p = FIRST ? (uint32_t)(base + e) : p16[FIRST ? 0 : it];
-      const uint32_t vv = PACKED ? ((uint32_t)sk[e + 1] & PK_POS_MASK) : v16[PACKED ? 0 : it];
+      const uint32_t vv = (PACKED ? (uint32_t)sk[e + 1] : v16[PACKED ? 0 : it]) & PK_POS_MASK;
       const uint32_t blk = p / g.stride;
       ub[it] = sing ? (uint32_t)Tx[(size_t)blk * g.stride + (vv ? vv - 1u : blk_len(g, blk) - 1u)] : 0u;
     }
@@ -649,7 +659,9 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
         if (!FIRST) keeps_rank = head_a == 0 || (key[head_a] >> 20) != (key[head_a - 1] >> 20);
       }
       const uint32_t p = FIRST ? (uint32_t)a : p16[FIRST ? 0 : it];
-      const uint32_t vv = PACKED ? ((uint32_t)sk[e + 1] & PK_POS_MASK) : v16[PACKED ? 0 : it];
+      const uint32_t vraw = PACKED ? (uint32_t)sk[e + 1] : v16[PACKED ? 0 : it];
+      const uint32_t vv = vraw & PK_POS_MASK;                    // the suffix (positions are below 2^20)
+      const uint32_t pb = PACKED ? (vraw >> PK2_PREV_SHIFT) & 0xFFu : vraw >> VAL_PREV_SHIFT;      // its carried byte, if any
       const uint32_t blk = p / g.stride;
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
       if (!keeps_rank && (hm_.halves <= 1 || (uint32_t)(vv >= hsplit) == half)) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
@@ -658,12 +670,12 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
         // a resolved suffix: its BWT byte goes straight to the output row (cyclic form: U[p] = T[suffix - 1], p in sorted-position
         // order) -- no suffix array is written, and the byte gathers overlap the rest of the regrouping instead of making a pass
         // of their own at the end; the sentinel form shifts the rows by the primary index, which is only known at the end: SA
-        if (U) U[p] = (uint8_t)ub[it];
+        if (U) U[p] = (uint8_t)(carried ? pb : ub[it]);
         else __builtin_nontemporal_store(vv, SA + p);
       } else {
         const uint32_t so = sbase + wp_s[wi] + (uint32_t)__popcll(~ms & lt);
         const uint32_t ho = hbase + wp_h[wi] + (uint32_t)__popcll(mh & ~ms & le);
-        __builtin_nontemporal_store(vv, nval + so); __builtin_nontemporal_store(p, npos + so); __builtin_nontemporal_store(ho - 1u, ngord + so);
+        __builtin_nontemporal_store(carried ? (vv | (pb << VAL_PREV_SHIFT)) : vv, nval + so); __builtin_nontemporal_store(p, npos + so); __builtin_nontemporal_store(ho - 1u, ngord + so);
       }
     }
   }
@@ -732,7 +744,7 @@ __device__ __forceinline__ void ts_fused_gather(const TsGather& tg, uint32_t nee
 #pragma unroll
   for (int s = 0; s < 16; s++) {
     const uint32_t blk = pp[s] / tg.g.stride, n = blk_len(tg.g, blk);
-    uint32_t j = pv[s] + tg.h;
+    uint32_t j = (pv[s] & PK_POS_MASK) + tg.h;       // (the top byte of val[] may carry the byte in front of the suffix)
     if (tg.cyclic) { if (j >= n) j %= n; }
     else if (j >= n) { j = 0; past |= 1u << s; }
     pp[s] = blk * tg.g.stride + j;               // (positions are 32 bits wide: bwt_run refuses more)
@@ -1164,10 +1176,11 @@ __global__ __launch_bounds__(256) void bwt_defer_scatter(uint32_t D, const uint6
 }
 
 __global__ __launch_bounds__(256) void bwt_flush_active(uint32_t A, const uint32_t* __restrict__ val, const uint32_t* __restrict__ pos,
-                                                        uint32_t* __restrict__ SA, Geom g, const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U) {
+                                                        uint32_t* __restrict__ SA, Geom g, const uint8_t* __restrict__ Tx, uint8_t* __restrict__ U, int carried) {
   for (uint64_t a = (uint64_t)blockIdx.x * 256 + threadIdx.x; a < A; a += (uint64_t)gridDim.x * 256) {
-    const uint32_t p = pos[a], v = val[a];
-    if (U) { const uint32_t blk = p / g.stride; U[p] = Tx[(size_t)blk * g.stride + (v ? v - 1u : blk_len(g, blk) - 1u)]; }
+    const uint32_t p = pos[a], v = val[a] & PK_POS_MASK;
+    if (U && carried) U[p] = (uint8_t)(val[a] >> VAL_PREV_SHIFT);
+    else if (U) { const uint32_t blk = p / g.stride; U[p] = Tx[(size_t)blk * g.stride + (v ? v - 1u : blk_len(g, blk) - 1u)]; }
     else SA[p] = v;
   }
 }
@@ -1215,6 +1228,7 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
     for (int it = 0; it < 16; it++) {
       const uint32_t p = (uint32_t)k16[it] & PK_POS_MASK;
       b01[it] = ((uint32_t)tx[p] << 8) | tx[p + 1 < n ? p + 1 : 0];          // (one unaligned 16-bit load instead: 720 -> 900 us)
+      b01[it] |= (uint32_t)tx[p ? p - 1 : n - 1] << 16;                     // the byte in front (nearly always the line of tx[p]): carried from here on
     }
   }
 #pragma unroll
@@ -1263,7 +1277,7 @@ __global__ __launch_bounds__(256) void bwt_phase2_records(const uint64_t* __rest
       const uint32_t head_a = hm ? (uint32_t)base + (uint32_t)wi * 64u + 63u - (uint32_t)__builtin_clzll(hm) : wp_head[wi] ? (uint32_t)base + wp_head[wi] - 1u : carry - 1u;
       const uint64_t k = k16[it];
       const uint32_t r1 = head_a - (uint32_t)seg0;
-      __builtin_nontemporal_store(((uint64_t)b01[it] << 48) | ((uint64_t)r1 << 28) | (k & ((1ull << (PK_SHIFT + 1)) - 1ull)), out + base + e);
+      __builtin_nontemporal_store(((uint64_t)(b01[it] & 0xFFFFu) << 48) | ((uint64_t)r1 << PK2_GSHIFT) | ((uint64_t)(b01[it] >> 16) << PK2_PREV_SHIFT) | (k & PK_POS_MASK), out + base + e);
     }
   }
 }
@@ -1542,6 +1556,8 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   const bool direct = cyclic && env_direct;
   const uint8_t* dT = direct ? d_T : nullptr;
   uint8_t* dU = direct ? d_U : nullptr;
+  const int gs1 = two_phase ? PK2_GSHIFT : packed ? PK_SHIFT : 0;      // group key of the round-1 records = key >> gs1
+  const int carried = two_phase && direct ? 1 : 0;                      // two-phase records (then val[]) carry the byte in front of their suffix
   for (;;) {
     if (rounds == 0) {
       if (packed) {
@@ -1558,13 +1574,13 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     if (rounds == 0 && packed && sweeps && env_halves == 3) {          // two launches, no counting pass (see bwt_apply)
       const HalfMap hm{2u, 0u, stride};
       hipLaunchKernelGGL((bwt_apply<true, true, 1>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4, gs1, carried);
       hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
       CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
       hipLaunchKernelGGL((bwt_apply<true, true, 2>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
+                         w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4, gs1, carried);
     } else {
-    hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, (rounds == 0 && packed) ? PK_SHIFT : 0, w.counters + 4);
+    hipLaunchKernelGGL(bwt_flags, dim3(T), dim3(256), 0, s, w.key[c], A, w.tile_cnt, T, rounds == 0 ? gs1 : 0, w.counters + 4, rounds == 0 ? stride : 0u);
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
     CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
     if (rounds == 0) {
@@ -1575,11 +1591,11 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
         grid = 8u * ((nb + 7u) / 8u) * 2u * hm.slots;
       }
       if (packed) hipLaunchKernelGGL((bwt_apply<true, true>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                                     w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
+                                     w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4, gs1, carried);
       else hipLaunchKernelGGL((bwt_apply<true, false>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                              w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4);
+                              w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4, gs1, carried);
     } else hipLaunchKernelGGL((bwt_apply<false, false>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride}, dT, dU, w.counters + 4);
+                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride}, dT, dU, w.counters + 4, gs1, carried);
     }
     // the host only needs the counters of the tile scan: it waits for THAT kernel and queues the next round behind the regroup
     // kernel while it runs (a stream synchronisation here left the GPU idle for ~20 us per round)
@@ -1592,7 +1608,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     A = A2; ngroups = NG;
     if (A == 0) break;
     if (cyclic && h >= max_n) {     // only groups of equal rotations are left
-      hipLaunchKernelGGL(bwt_flush_active, dim3((A + 255) / 256), dim3(256), 0, s, A, w.val[c], w.pos[pc], w.SA, g, dT, dU);
+      hipLaunchKernelGGL(bwt_flush_active, dim3((A + 255) / 256), dim3(256), 0, s, A, w.val[c], w.pos[pc], w.SA, g, dT, dU, carried);
       break;
     }
     if (rounds > 40) return CJS_E_HIP;    // cannot happen: depth doubles every round
