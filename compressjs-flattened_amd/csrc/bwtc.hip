@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -369,26 +370,50 @@ __global__ __launch_bounds__(64) void bwtc_defsum(MtfBufs mb, uint64_t* __restri
 // ---------------------------------------------------------------- host: framing + serial range coder
 namespace {
 
-struct HostCoder {                                      // RangeCoder encode side (J/BWTC_joined_.js:40-153)
+// RangeCoder encode side (J/BWTC_joined_.js:40-153).  The interval arithmetic is one serial chain over the whole file, but it
+// is TWO chains: `range` never depends on `low` (range' = f(range, step); low only receives r * lt and is shifted when range is).
+// In split mode (default) the calling thread runs the range chain alone and leaves one record per step -- the addend r * lt and
+// the number of byte shifts in front of it -- in a ring of buffers; a second host thread replays them on `low` (carry
+// propagation, pending 0xFF bytes, output).  Same bytes as the one-thread form (CJS_BWTC_SPLIT_CODER=0), which runs both
+// chains in one loop at ~5 ns per step.
+struct HostCoder {
   std::vector<uint8_t>& out;                            // bytes [0, len) are output; the vector is kept larger (reserve())
-  uint8_t* data = nullptr;
+  static constexpr uint32_t RING = 8, RCAP = 1u << 15;
+  std::vector<uint64_t> ring[RING];
+  uint32_t ring_n[RING];
+  std::thread low_thread;
+  // the two threads of the split mode write their own state at every step: each side on cache lines of its own (with range
+  // and low on one line the pair ran 8x slower than one thread)
+  alignas(128) uint8_t* data = nullptr;                 // ---- low side
   size_t len = 0;
-  uint32_t low = 0, range = 0x80000000u, help = 0, bytecount = 0;
+  uint32_t low = 0, help = 0, bytecount = 0;
   int buffer = 0;
+  alignas(128) uint32_t range = 0x80000000u;            // ---- range side
+  bool split = false;
+  uint64_t* cur = nullptr;
+  uint32_t cur_n = 0;
+  alignas(128) std::atomic<uint64_t> produced{0};       // written by the range side
+  alignas(128) std::atomic<uint64_t> consumed{0};       // written by the low side
+  alignas(128) std::atomic<bool> closing{false};
+  std::atomic<bool> failed{false};                      // the low thread ran out of memory (it keeps draining the ring)
   explicit HostCoder(std::vector<uint8_t>& o) : out(o) { len = o.size(); reserve(4096); }
+  ~HostCoder() { stop_thread(); }
   void reserve(size_t extra) {                          // room for `extra` more bytes (a coder step emits at most 3)
     if (len + extra > out.size()) out.resize(std::max(out.size() * 2, len + extra));
     data = out.data();
   }
+  void reserve_steps(size_t nsteps) { if (!split) reserve(3 * nsteps + help + 4096); }      // (split mode: the low thread reserves per buffer)
   inline void emit(uint8_t b) { data[len++] = b; }
   void start(int c, uint32_t initlen) { low = 0; range = 0x80000000u; buffer = c; help = 0; bytecount = initlen; }
+  // one byte shift of the low chain: what leaves (or stays pending) is decided by low alone
+  inline void shift_low() {
+    if (low < (0xFFu << 23)) { emit((uint8_t)buffer); for (; help; help--) emit(0xFF); buffer = (low >> 23) & 0xFF; }
+    else if (low & 0x80000000u) { emit((uint8_t)(buffer + 1)); for (; help; help--) emit(0x00); buffer = (low >> 23) & 0xFF; }
+    else help++;
+    low = (low << 8) & 0x7FFFFFFFu; bytecount++;
+  }
   inline void normalize() {
-    while (range <= 0x00800000u) {
-      if (low < (0xFFu << 23)) { emit((uint8_t)buffer); for (; help; help--) emit(0xFF); buffer = (low >> 23) & 0xFF; }
-      else if (low & 0x80000000u) { emit((uint8_t)(buffer + 1)); for (; help; help--) emit(0x00); buffer = (low >> 23) & 0xFF; }
-      else help++;
-      range <<= 8; low = (low << 8) & 0x7FFFFFFFu; bytecount++;
-    }
+    while (range <= 0x00800000u) { shift_low(); range <<= 8; }
   }
   // normalize() for the step loop: whether a byte leaves is a coin flip per step, so the usual case (at most one
   // byte, no pending carry bytes, no carry) is written without a branch: unconditional store, conditional advance
@@ -402,7 +427,71 @@ struct HostCoder {                                      // RangeCoder encode sid
     range = need ? range << 8 : range;
     bytecount += need;
   }
+  // ---- split mode, range side (calling thread)
+  void start_split() {
+    for (auto& r : ring) r.assign(RCAP, 0ull);
+    cur = ring[0].data(); cur_n = 0; split = true;
+    low_thread = std::thread([this] { low_loop(); });
+  }
+  inline uint32_t shifts_needed() {                     // (zero or one shift is a coin flip per step: no branch for it)
+    if (__builtin_expect(range <= 0x00008000u, 0)) { uint32_t k = 0; while (range <= 0x00800000u) { range <<= 8; k++; } return k; }
+    const uint32_t k = range <= 0x00800000u;
+    range <<= (k << 3);
+    return k;
+  }
+  inline void push(uint32_t add, uint32_t k) {
+    cur[cur_n++] = (uint64_t)add | ((uint64_t)k << 32);
+    if (cur_n == RCAP) hand_over();
+  }
+  void hand_over() {                                    // the full (or last) buffer goes to the low thread
+    const uint64_t p = produced.load(std::memory_order_relaxed);
+    ring_n[p % RING] = cur_n;
+    produced.store(p + 1, std::memory_order_release);
+    while (p + 1 - consumed.load(std::memory_order_acquire) >= RING) std::this_thread::yield();
+    cur = ring[(p + 1) % RING].data(); cur_n = 0;
+  }
+  // ---- split mode, low side (its own thread): replays (shifts, addend) on low
+  void low_loop() {
+    for (;;) {
+      const uint64_t c = consumed.load(std::memory_order_relaxed);
+      uint32_t spins = 0;
+      while (produced.load(std::memory_order_acquire) == c) {
+        if (closing.load(std::memory_order_acquire) && produced.load(std::memory_order_acquire) == c) return;
+        if (++spins > 64) std::this_thread::yield();
+      }
+      const uint64_t* rec = ring[c % RING].data();
+      uint32_t n = ring_n[c % RING];
+      if (!failed.load(std::memory_order_relaxed)) {
+        try { reserve(4 * (size_t)n + help + 64); } catch (...) { failed.store(true, std::memory_order_relaxed); }
+      }
+      if (failed.load(std::memory_order_relaxed)) n = 0;
+      for (uint32_t i = 0; i < n; i++) {
+        const uint64_t e = rec[i];
+        uint32_t k = (uint32_t)(e >> 32);
+        // the usual case without a branch, as in normalize_step(): at most one shift, no pending bytes, no carry
+        const uint32_t need = k;
+        if (__builtin_expect((k > 1u) | ((k != 0u) & (uint32_t)((low >= (0xFFu << 23)) | (help != 0))), 0)) { for (; k; k--) shift_low(); }
+        else {
+          data[len] = (uint8_t)buffer;
+          len += need;
+          buffer = need ? (int)((low >> 23) & 0xFF) : buffer;
+          low = need ? (low << 8) & 0x7FFFFFFFu : low;
+          bytecount += need;
+        }
+        low += (uint32_t)e;
+      }
+      consumed.store(c + 1, std::memory_order_release);
+    }
+  }
+  void stop_thread() {
+    if (!low_thread.joinable()) return;
+    if (cur_n) hand_over();
+    closing.store(true, std::memory_order_release);
+    low_thread.join();
+    split = false;
+  }
   inline void freq(uint32_t sy, uint32_t lt, uint32_t tot) {
+    if (split) { const uint32_t k = shifts_needed(); const uint32_t r = range / tot, tmp = r * lt; range = (lt + sy < tot) ? r * sy : range - tmp; push(tmp, k); return; }
     normalize();
     const uint32_t r = range / tot, tmp = r * lt;
     low += tmp;
@@ -411,21 +500,30 @@ struct HostCoder {                                      // RangeCoder encode sid
   // same arithmetic with the division replaced by a multiply with a 64-bit reciprocal: the quotient sits on the serial
   // (low, range) chain, the reciprocal (looked up by tot, which comes from the step list) does not
   inline void freq_rcp(uint32_t sy, uint32_t lt, uint32_t tot, const uint64_t* rcp) {
-    normalize_step();
     // rcp[tot] = floor(2^64 / tot) + 1: the high half of range * rcp is floor(range / tot) exactly (range < 2^32, tot < 2^17:
     // range * (rcp*tot - 2^64) < 2^49 < 2^64), so no correction step sits on the chain
+    if (split) {
+      const uint32_t k = shifts_needed();
+      const uint32_t r = (uint32_t)(((unsigned __int128)range * rcp[tot]) >> 64), tmp = r * lt;
+      range = (lt + sy < tot) ? r * sy : range - tmp;
+      push(tmp, k);
+      return;
+    }
+    normalize_step();
     const uint32_t r = (uint32_t)(((unsigned __int128)range * rcp[tot]) >> 64);
     const uint32_t tmp = r * lt;
     low += tmp;
     range = (lt + sy < tot) ? r * sy : range - tmp;
   }
   inline void shift(uint32_t sy, uint32_t lt, int sh) {
+    if (split) { const uint32_t k = shifts_needed(); const uint32_t r = range >> sh, tmp = r * lt; range = ((lt + sy) >> sh) ? range - tmp : r * sy; push(tmp, k); return; }
     normalize();
     const uint32_t r = range >> sh, tmp = r * lt;
     low += tmp;
     if ((lt + sy) >> sh) range -= tmp; else range = r * sy;
   }
   void finish() {
+    if (split) { const uint32_t k = shifts_needed(); push(0u, k); stop_thread(); }      // the closing normalisation as a record; then the low side is ours again
     reserve(help + 16);
     normalize();
     bytecount += 5;
@@ -593,6 +691,8 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
   for (int i = nv - 1; i >= 1; i--) o.push_back(vb[i]);
   HostCoder coder(o);
   coder.start(vb[0], 1);                                             // :1700 (the last varint byte is the coder's first byte)
+  static const bool env_split_coder = getenv("CJS_BWTC_SPLIT_CODER") == nullptr || atoi(getenv("CJS_BWTC_SPLIT_CODER")) != 0;
+  if (env_split_coder && nb) coder.start_split();                    // range chain here, low chain on a second host thread
   coder.shift(1, (uint32_t)level, 8);                                // encodeByte(level) :1706
   int rc = 0;
   const auto T0 = std::chrono::steady_clock::now();
@@ -668,7 +768,7 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
       if (k + 1 < nb) rc = fetch(k + 1);
       if (rc) break;
       const auto Tc = std::chrono::steady_clock::now();
-      coder.reserve(3 * (size_t)B.nsteps[r] + coder.help + 4096);     // everything this block can emit
+      coder.reserve_steps(B.nsteps[r]);                              // everything this block can emit
       const uint32_t length = k + 1 == nb ? J.n_last : bs;
       if (length == bs) coder.freq(1, 0, 3);                         // "full size block" :1734
       else { coder.freq(1, 1, 3); logdist(coder, (int)bs, length); } // "short block" :1737-1738
@@ -713,9 +813,10 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     }
   }
   if (rc) return rc;
-  coder.reserve(coder.help + 64);
+  coder.reserve_steps(64);
   coder.freq(1, 2, 3);                                               // "no more blocks" :1823
   coder.finish();
+  if (coder.failed.load()) return CJS_E_OUT_OF_MEMORY;
   uint8_t* host = (uint8_t*)malloc(o.size() ? o.size() : 1);
   if (!host) return CJS_E_OUT_OF_MEMORY;
   memcpy(host, o.data(), o.size());

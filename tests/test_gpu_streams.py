@@ -412,13 +412,14 @@ def test_sharded_bwtc_compress_equals_golden(hip, monkeypatch):
         rc, out = hip.bwtc_compress(data, 9)
         monkeypatch.delenv("CJS_DEVICES")
         assert rc == 0 and out.size == case["out_len"] and support.sha256(out) == case["out_sha256"], ndev
-    # small first batch / single batch give the same stream too
-    for fb in ("0", "1", "3"):
+    # small first batch / single batch give the same stream too, and so does the one-thread form of the range coder (the
+    # default runs the range chain and the low chain on two host threads)
+    for env in ({"CJS_BWTC_FIRST_BATCH": "0"}, {"CJS_BWTC_FIRST_BATCH": "1"}, {"CJS_BWTC_FIRST_BATCH": "3"}, {"CJS_BWTC_SPLIT_CODER": "0"}):
         import subprocess, sys as _sys
         code = ("import sys; sys.path.insert(0, 'tests'); import torch, support, recipes; "
                 "d = recipes.textgen(10000000, 1); rc, out = support.HipLib().bwtc_compress(d, 9); print(rc, support.sha256(out))")
-        o = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, CJS_BWTC_FIRST_BATCH=fb), cwd=ROOT, timeout=300)
-        assert o.returncode == 0 and o.stdout.split() == ["0", case["out_sha256"]], (fb, o.stderr[-800:])
+        o = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), cwd=ROOT, timeout=300)
+        assert o.returncode == 0 and o.stdout.split() == ["0", case["out_sha256"]], (env, o.stderr[-800:])
 
 
 def test_multistream_with_more_than_65535_blocks(hip, oracle):
