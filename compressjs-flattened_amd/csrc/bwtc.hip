@@ -398,6 +398,9 @@ struct HostCoder {
   alignas(128) std::atomic<uint64_t> consumed{0};       // written by the low side
   alignas(128) std::atomic<bool> closing{false};
   std::atomic<bool> failed{false};                      // the low thread ran out of memory (it keeps draining the ring)
+  uint64_t dbg_full_spins = 0;                          // range side: polls while the ring was full (CJS_DEBUG)
+  alignas(128) uint64_t dbg_empty_spins = 0;            // low side: polls while the ring was empty
+  int dbg_low_cpu[2] = {-1, -1};
   explicit HostCoder(std::vector<uint8_t>& o) : out(o) { len = o.size(); reserve(4096); }
   ~HostCoder() { stop_thread(); }
   void reserve(size_t extra) {                          // room for `extra` more bytes (a coder step emits at most 3)
@@ -436,36 +439,51 @@ struct HostCoder {
     low_thread = std::thread([this] { low_loop(); });
     keep_off_my_core(low_thread);
   }
-  // The two chains are latency-bound loops: on the two hardware threads of ONE core they run at the pace of one thread (the
-  // pair then takes ~320 ms per 100 MB instead of ~205).  The low thread is kept off the core this thread runs on: its
-  // affinity = the allowed CPUs minus that core's hardware threads (nothing is changed when the topology cannot be read).
+  // Where the second thread runs decides what the split is worth (2-socket EPYC host of the MI355X box, 100 MB): on another core
+  // of the caller's L3 domain 169-200 ms of coding, elsewhere on the caller's socket 200-225 ms, on the OTHER socket 310-360 ms
+  // (every ring line the range side writes was last read over there: slower than one thread, 308 ms), on the caller's own core
+  // (its second hardware thread) ~320 ms.  So the low thread's affinity is set to the CPUs that share the caller's L3 minus the
+  // caller's core; if that cannot be read, to the caller's package minus its core; if that cannot be read either, nothing is
+  // changed.  The caller's own affinity is never touched.  CJS_BWTC_NO_AFFINITY=1 switches this off.
+  static bool read_cpu_list(const char* fmt, int cpu, cpu_set_t* set) {
+    char path[128];
+    snprintf(path, sizeof path, fmt, cpu);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char line[512] = {0};
+    const bool ok = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    CPU_ZERO(set);
+    int n = 0;
+    for (char* p = line; *p;) {                          // "a,b-c,d" lists
+      char* e = nullptr;
+      const long a = strtol(p, &e, 10);
+      if (e == p) break;
+      long b2 = a;
+      if (*e == '-') { p = e + 1; b2 = strtol(p, &e, 10); }
+      for (long c = a; c <= b2 && c < CPU_SETSIZE; c++) if (c >= 0) { CPU_SET((int)c, set); n++; }
+      if (*e != ',') break;
+      p = e + 1;
+    }
+    return n > 0;
+  }
   static void keep_off_my_core(std::thread& t) {
     static const bool off = getenv("CJS_BWTC_NO_AFFINITY") != nullptr;
     const int cpu = sched_getcpu();
     if (off || cpu < 0) return;
-    char path[96];
-    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
-    FILE* f = fopen(path, "r");
-    if (!f) return;
-    char line[128] = {0};
-    const bool ok = fgets(line, sizeof line, f) != nullptr;
-    fclose(f);
-    cpu_set_t mine, allowed;
-    CPU_ZERO(&mine);
-    if (!ok || sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
-    for (char* p = line; *p;) {                          // "a,b" or "a-b" lists
-      char* e = nullptr;
-      const long a = strtol(p, &e, 10);
-      if (e == p) break;
-      long b = a;
-      if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
-      for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) CPU_SET((int)c, &mine);
-      p = (*e == ',') ? e + 1 : e;
-      if (*e != ',' ) break;
+    cpu_set_t mine, near, allowed;
+    if (!read_cpu_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu, &mine)) return;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    const char* domains[2] = {"/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", "/sys/devices/system/cpu/cpu%d/topology/package_cpus_list"};
+    for (const char* d : domains) {
+      if (!read_cpu_list(d, cpu, &near)) continue;
+      cpu_set_t want;
+      CPU_ZERO(&want);
+      int left = 0;
+      for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &near) && CPU_ISSET(c, &allowed) && !CPU_ISSET(c, &mine)) { CPU_SET(c, &want); left++; }
+      if (left > 0) { (void)pthread_setaffinity_np(t.native_handle(), sizeof want, &want); return; }
     }
-    int left = 0;
-    for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) { if (CPU_ISSET(c, &mine)) CPU_CLR(c, &allowed); else left++; }
-    if (left > 0) (void)pthread_setaffinity_np(t.native_handle(), sizeof allowed, &allowed);
   }
   inline uint32_t shifts_needed() {                     // (zero or one shift is a coin flip per step: no branch for it)
     if (__builtin_expect(range <= 0x00008000u, 0)) { uint32_t k = 0; while (range <= 0x00800000u) { range <<= 8; k++; } return k; }
@@ -481,17 +499,20 @@ struct HostCoder {
     const uint64_t p = produced.load(std::memory_order_relaxed);
     ring_n[p % RING] = cur_n;
     produced.store(p + 1, std::memory_order_release);
-    while (p + 1 - consumed.load(std::memory_order_acquire) >= RING) __builtin_ia32_pause();
+    while (p + 1 - consumed.load(std::memory_order_acquire) >= RING) { __builtin_ia32_pause(); dbg_full_spins++; }
     cur = ring[(p + 1) % RING].data(); cur_n = 0;
   }
   // ---- split mode, low side (its own thread): replays (shifts, addend) on low
   void low_loop() {
+    dbg_low_cpu[0] = sched_getcpu();
     for (;;) {
+      dbg_low_cpu[1] = sched_getcpu();
       const uint64_t c = consumed.load(std::memory_order_relaxed);
       uint32_t spins = 0;
       while (produced.load(std::memory_order_acquire) == c) {
         if (closing.load(std::memory_order_acquire) && produced.load(std::memory_order_acquire) == c) return;
         __builtin_ia32_pause();                          // (a polling loop without it starves the other hardware thread of the core)
+        dbg_empty_spins++;
         if (++spins > 4096) { std::this_thread::yield(); spins = 0; }
       }
       const uint64_t* rec = ring[c % RING].data();
@@ -727,6 +748,7 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
   HostCoder coder(o);
   coder.start(vb[0], 1);                                             // :1700 (the last varint byte is the coder's first byte)
   static const bool env_split_coder = getenv("CJS_BWTC_SPLIT_CODER") == nullptr || atoi(getenv("CJS_BWTC_SPLIT_CODER")) != 0;
+  const int dbg_cpu0 = sched_getcpu();
   if (env_split_coder && nb) coder.start_split();                    // range chain here, low chain on a second host thread
   coder.shift(1, (uint32_t)level, 8);                                // encodeByte(level) :1706
   int rc = 0;
@@ -850,8 +872,11 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
   if (rc) return rc;
   coder.reserve_steps(64);
   coder.freq(1, 2, 3);                                               // "no more blocks" :1823
+  const int dbg_cpu1 = sched_getcpu();
   coder.finish();
   if (coder.failed.load()) return CJS_E_OUT_OF_MEMORY;
+  if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwtc] split coder: range side on cpu %d -> %d, low side on cpu %d -> %d, polls with the ring full %llu, empty %llu\n", dbg_cpu0, dbg_cpu1,
+                                   coder.dbg_low_cpu[0], coder.dbg_low_cpu[1], (unsigned long long)coder.dbg_full_spins, (unsigned long long)coder.dbg_empty_spins);
   uint8_t* host = (uint8_t*)malloc(o.size() ? o.size() : 1);
   if (!host) return CJS_E_OUT_OF_MEMORY;
   memcpy(host, o.data(), o.size());
