@@ -23,6 +23,8 @@ constexpr int PD_GROUPS = 80;            // groups per data-packing tile (4000 s
 
 // phase clock of workgroup 0 (CJS_DEBUG only): 100 MHz ticks at the marks of huff_block
 __device__ uint64_t g_huff_clk[32];
+__device__ uint64_t g_bt_clk[8];          // table-build phase clock of (block 0, wave 0), CJS_DEBUG
+#define BT_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bt_clk[i] = wall_clock64(); } while (0)
 #define HB_MARK(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) g_huff_clk[i] = wall_clock64(); } while (0)
 
 // ------------------------------------------------------------------ allocator (lane 0, LDS array)
@@ -39,37 +41,69 @@ __device__ __forceinline__ int ha_first(const int* a, int len, int i, int nodes_
   }
   return k;
 }
-__device__ __forceinline__ void ha_alloc(int* a, int len, int maxlen) {                             // Bzip2:1275-1298
-  if (len == 2) { a[1] = 1; a[0] = 1; return; }
-  if (len == 1) { a[0] = 1; return; }
-  // pass 1: extended parent pointers (Bzip2:1162-1186)
+// pass 1 (one lane): extended parent pointers (Bzip2:1162-1186); false when len < 3 (lengths written, nothing left to do)
+__device__ __forceinline__ bool ha_pass1(int* a, int len) {
+  if (len == 2) { a[1] = 1; a[0] = 1; return false; }
+  if (len == 1) { a[0] = 1; return false; }
   a[0] += a[1];
-  {
-    // the two queue fronts live in registers two deep (H = a[head], Hn = a[head+1], T = a[top], Tn = a[top+1]), so the
-    // LDS reads that refill them overlap the comparisons instead of sitting on the critical path
-    int head = 0, top = 2;
-    int H = a[0], Hn = 0;
-    int T = top < len ? a[top] : 0, Tn = top + 1 < len ? a[top + 1] : 0;
-    for (int tail = 1; tail < len - 1; tail++) {
-      int w;
-      if (top >= len || H < T) { w = H; a[head++] = tail; H = Hn; if (head + 1 < tail) Hn = a[head + 1]; }
-      else { w = T; top++; T = Tn; if (top + 1 < len) Tn = a[top + 1]; }
-      if (top >= len || (head < tail && H < T)) { w += H; a[head++] = tail + len; H = Hn; if (head + 1 < tail) Hn = a[head + 1]; }
-      else { w += T; top++; T = Tn; if (top + 1 < len) Tn = a[top + 1]; }
-      a[tail] = w;
-      if (head == tail) H = w; else if (head + 1 == tail) Hn = w;
+  // the two queue fronts live in registers two deep (H = a[head], Hn = a[head+1], T = a[top], Tn = a[top+1]), so the
+  // LDS reads that refill them overlap the comparisons instead of sitting on the critical path
+  int head = 0, top = 2;
+  int H = a[0], Hn = 0;
+  int T = top < len ? a[top] : 0, Tn = top + 1 < len ? a[top + 1] : 0;
+  for (int tail = 1; tail < len - 1; tail++) {
+    int w;
+    if (top >= len || H < T) { w = H; a[head++] = tail; H = Hn; if (head + 1 < tail) Hn = a[head + 1]; }
+    else { w = T; top++; T = Tn; if (top + 1 < len) Tn = a[top + 1]; }
+    if (top >= len || (head < tail && H < T)) { w += H; a[head++] = tail + len; H = Hn; if (head + 1 < tail) Hn = a[head + 1]; }
+    else { w += T; top++; T = Tn; if (top + 1 < len) Tn = a[top + 1]; }
+    a[tail] = w;
+    if (head == tail) H = w; else if (head + 1 == tail) Hn = w;
+  }
+  return true;
+}
+// Passes 2 and 3 by the whole wave.  ha_first() is a search for the first node whose parent lies above `limit`, and parents
+// are non-decreasing along the array, so it is ONE ballot per 64 nodes over a register copy of the parent pointers instead of
+// ~10 dependent LDS reads of one lane (~60 ns each); the fills of pass 3 are one masked store.  Only nodes at or below `limit`
+// are searched: pass 3 never overwrites those (it fills from the top down to `next` >= `first` > limit), and the node at `limit`
+// always qualifies (its parent was created after it), which is the case in which the serial rule stays inside [lo, limit] too.
+// Should it not qualify, the serial rule is applied as it stands.  All control values are wave-uniform.
+__device__ __forceinline__ int haw_first(const int (&pm)[5], const int* a, int len, int limit, int lo) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    if (64 * t <= limit) {
+      const int idx = lane + 64 * t;
+      const uint64_t m = __ballot(idx >= lo && idx <= limit && pm[t] > limit);
+      if (m) return 64 * t + (int)__builtin_ctzll(m);
     }
   }
+  return ha_first(a, len, limit, lo);
+}
+__device__ __forceinline__ void haw_fill(int* a, int lo, int hi, int x) {          // a[lo..hi] = x
+  const int lane = lane_id();
+#pragma unroll
+  for (int t = 0; t < 5; t++) { const int idx = lane + 64 * t; if (idx >= lo && idx <= hi) a[idx] = x; }
+}
+__device__ __forceinline__ void ha_passes23_wave(int* a, int len, int maxlen) {
+  const int lane = lane_id();
+  int pm[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) { const int idx = lane + 64 * t; pm[t] = idx < len ? ha_mod(a[idx], len) : 0; }
+  const int root0 = __builtin_amdgcn_readfirstlane(pm[0]);                         // ha_mod(a[0], len)
+  BT_MARK(2);
   // pass 2: nodes to relocate (Bzip2:1195-1204)
   int reloc = len - 2;
-  for (int depth = 1; depth < maxlen - 1 && reloc > 1; depth++) reloc = ha_first(a, len, reloc - 1, 0);
+  for (int depth = 1; depth < maxlen - 1 && reloc > 1; depth++) reloc = haw_first(pm, a, len, reloc - 1, 0);
+  BT_MARK(3);
   // pass 3
-  if (ha_mod(a[0], len) >= reloc) {                                                      // Bzip2:1211-1226
+  if (root0 >= reloc) {                                                            // Bzip2:1211-1226
     int first = len - 2, next = len - 1;
     for (int depth = 1, avail = 2; avail > 0; depth++) {
       const int last = first;
-      first = ha_first(a, len, last - 1, 0);
-      for (int i = avail - (last - first); i > 0; i--) a[next--] = depth;
+      first = haw_first(pm, a, len, last - 1, 0);
+      const int cnt = avail - (last - first);
+      if (cnt > 0) { haw_fill(a, next - cnt + 1, next, depth); next -= cnt; }
       avail = (last - first) << 1;
     }
   } else {                                                                          // Bzip2:1235-1264
@@ -80,98 +114,17 @@ __device__ __forceinline__ void ha_alloc(int* a, int len, int maxlen) {         
     int left = insert_depth == 1 ? reloc - 2 : reloc;
     for (int avail = depth << 1; avail > 0; depth++) {
       const int last = first;
-      first = first <= reloc ? first : ha_first(a, len, last - 1, reloc);
+      first = first <= reloc ? first : haw_first(pm, a, len, last - 1, reloc);
       int offset = 0;
       if (depth >= insert_depth) { offset = 1 << (depth - insert_depth); if (left < offset) offset = left; }
-      else if (depth == insert_depth - 1) { offset = 1; if (a[first] == last) first++; }
-      for (int i = avail - (last - first + offset); i > 0; i--) a[next--] = depth;
-      left -= offset;
-      avail = (last - first + offset) << 1;
-    }
-  }
-}
-
-// ---- the same allocator with the node array in the wave's registers (entry i = register i / 64 of lane i % 64) and every
-// index, weight and loop variable wave-uniform: reads are v_readlane, writes a compare + select, the control flow is scalar.  The
-// LDS form above runs on one lane and waits ~100+ cycles for every dependent a[i]; here an access costs a few cycles
-// (build of one text table, 100 symbols: 47 -> see DESIGN us).  Same passes, same tie-breaking (Bzip2:1135-1298).
-struct HaRegs { int v[5]; };           // 320 entries >= MAXSYM
-__device__ __forceinline__ int hr_get(const HaRegs& A, int i) {
-  const int l = i & 63, hi = i >> 6;
-  const int r0 = __builtin_amdgcn_readlane(A.v[0], l), r1 = __builtin_amdgcn_readlane(A.v[1], l);
-  if (hi < 2) return hi ? r1 : r0;
-  const int r2 = __builtin_amdgcn_readlane(A.v[2], l), r3 = __builtin_amdgcn_readlane(A.v[3], l), r4 = __builtin_amdgcn_readlane(A.v[4], l);
-  return hi == 2 ? r2 : hi == 3 ? r3 : r4;
-}
-__device__ __forceinline__ void hr_set(HaRegs& A, int i, int x) {       // (no v_writelane builtin in this compiler: compare + select)
-  const int hi = i >> 6;
-  const bool me = lane_id() == (i & 63);
-  if (hi == 0) A.v[0] = me ? x : A.v[0];
-  else if (hi == 1) A.v[1] = me ? x : A.v[1];
-  else if (hi == 2) A.v[2] = me ? x : A.v[2];
-  else if (hi == 3) A.v[3] = me ? x : A.v[3];
-  else A.v[4] = me ? x : A.v[4];
-}
-// a[lo..hi] = x (all lanes at once)
-__device__ __forceinline__ void hr_fill(HaRegs& A, int lo, int hi, int x) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int k = 0; k < 5; k++) { const int idx = k * 64 + lane; if (idx >= lo && idx <= hi) A.v[k] = x; }
-}
-__device__ __forceinline__ int hr_first(const HaRegs& A, int len, int i, int nodes_to_move) {
-  const int limit = i;
-  int k = len - 2;
-  while (i >= nodes_to_move && ha_mod(hr_get(A, i), len) > limit) { k = i; i -= (limit - i + 1); }
-  if (i < nodes_to_move - 1) i = nodes_to_move - 1;
-  while (k > i + 1) {
-    const int mid = (i + k) >> 1;
-    if (ha_mod(hr_get(A, mid), len) > limit) k = mid; else i = mid;
-  }
-  return k;
-}
-__device__ __forceinline__ void hr_alloc(HaRegs& A, int len, int maxlen) {
-  if (len == 2) { hr_set(A, 1, 1); hr_set(A, 0, 1); return; }
-  if (len == 1) { hr_set(A, 0, 1); return; }
-  hr_set(A, 0, hr_get(A, 0) + hr_get(A, 1));
-  {
-    int head = 0, top = 2;
-    int H = hr_get(A, 0), Hn = 0;
-    int T = top < len ? hr_get(A, top) : 0, Tn = top + 1 < len ? hr_get(A, top + 1) : 0;
-    for (int tail = 1; tail < len - 1; tail++) {
-      int w;
-      if (top >= len || H < T) { w = H; hr_set(A, head++, tail); H = Hn; if (head + 1 < tail) Hn = hr_get(A, head + 1); }
-      else { w = T; top++; T = Tn; if (top + 1 < len) Tn = hr_get(A, top + 1); }
-      if (top >= len || (head < tail && H < T)) { w += H; hr_set(A, head++, tail + len); H = Hn; if (head + 1 < tail) Hn = hr_get(A, head + 1); }
-      else { w += T; top++; T = Tn; if (top + 1 < len) Tn = hr_get(A, top + 1); }
-      hr_set(A, tail, w);
-      if (head == tail) H = w; else if (head + 1 == tail) Hn = w;
-    }
-  }
-  int reloc = len - 2;
-  for (int depth = 1; depth < maxlen - 1 && reloc > 1; depth++) reloc = hr_first(A, len, reloc - 1, 0);
-  if (ha_mod(hr_get(A, 0), len) >= reloc) {
-    int first = len - 2, next = len - 1;
-    for (int depth = 1, avail = 2; avail > 0; depth++) {
-      const int last = first;
-      first = hr_first(A, len, last - 1, 0);
-      const int cnt = avail - (last - first);
-      if (cnt > 0) { hr_fill(A, next - cnt + 1, next, depth); next -= cnt; }
-      avail = (last - first) << 1;
-    }
-  } else {
-    const unsigned rm1 = (unsigned)(reloc - 1);
-    const int insert_depth = maxlen - (rm1 ? 32 - __builtin_clz(rm1) : 0);
-    int first = len - 2, next = len - 1;
-    int depth = insert_depth == 1 ? 2 : 1;
-    int left = insert_depth == 1 ? reloc - 2 : reloc;
-    for (int avail = depth << 1; avail > 0; depth++) {
-      const int last = first;
-      first = first <= reloc ? first : hr_first(A, len, last - 1, reloc);
-      int offset = 0;
-      if (depth >= insert_depth) { offset = 1 << (depth - insert_depth); if (left < offset) offset = left; }
-      else if (depth == insert_depth - 1) { offset = 1; if (hr_get(A, first) == last) first++; }
+      else if (depth == insert_depth - 1) {
+        offset = 1;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (__builtin_amdgcn_readfirstlane(a[first]) == last) first++;             // (the array as it stands: fills included, as in the serial form)
+      }
       const int cnt = avail - (last - first + offset);
-      if (cnt > 0) { hr_fill(A, next - cnt + 1, next, depth); next -= cnt; }
+      if (cnt > 0) { haw_fill(a, next - cnt + 1, next, depth); next -= cnt; }
       left -= offset;
       avail = (last - first + offset) << 1;
     }
@@ -179,12 +132,12 @@ __device__ __forceinline__ void hr_alloc(HaRegs& A, int len, int maxlen) {
 }
 
 // One wave builds one table: freq[0..n) -> lens[0..n).  key/work are per-table LDS scratch (n entries).
-// (forced inline: as a call the LDS pointers are generic and every access a flat_load / flat_store)
-#ifndef CJS_HA_REGS
-#define CJS_HA_REGS 1
-#endif
+// (forced inline: as a call the LDS pointers are generic and every access a flat_load / flat_store.  Pass 1 of the allocator
+// stays on one lane: a variant with the node array in the wave's registers -- v_readlane reads, scalar control flow -- ran its
+// ~600 dependent steps no faster)
 __device__ __forceinline__ void build_table_wave(const uint32_t* freq, uint8_t* lens, uint32_t* key, int* work, int n) {
   const int lane = lane_id();
+  BT_MARK(0);
   for (int i = lane; i < n; i += 64) key[i] = (freq[i] << 9) | (uint32_t)i;       // Bzip2:1881-1883
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -202,21 +155,17 @@ __device__ __forceinline__ void build_table_wave(const uint32_t* freq, uint8_t* 
   for (int t = 0, i = lane; t < 5; t++, i += 64) if (i < n) work[rk[t]] = (int)(freq[i]);   // sortedFreq
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
-#if CJS_HA_REGS
-  {
-    HaRegs A;
-#pragma unroll
-    for (int t = 0; t < 5; t++) A.v[t] = lane + 64 * t < n ? work[lane + 64 * t] : 0;
-    hr_alloc(A, __builtin_amdgcn_readfirstlane(n), MAX_BITS);
-#pragma unroll
-    for (int t = 0; t < 5; t++) if (lane + 64 * t < n) work[lane + 64 * t] = A.v[t];
-  }
-#else
-  if (lane == 0) ha_alloc(work, n, MAX_BITS);
-#endif
+  BT_MARK(1);
+  int go = 0;
+  if (lane == 0) go = ha_pass1(work, n) ? 1 : 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (__builtin_amdgcn_readfirstlane(go)) ha_passes23_wave(work, __builtin_amdgcn_readfirstlane(n), MAX_BITS);
+  BT_MARK(5);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
   for (int t = 0, i = lane; t < 5; t++, i += 64) if (i < n) lens[i] = (uint8_t)work[rk[t]];
+  BT_MARK(6);
 }
 
 struct HuffShared {
@@ -827,6 +776,13 @@ int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A
     }
     hipLaunchKernelGGL(hs_finish, dim3(nb), dim3(1024), 0, s, w.b, d_npos, d_asz, d_alist);
     CJS_HIP_TRY(hipGetLastError());
+    if (dbg) {
+      uint64_t clk[8];
+      CJS_HIP_TRY(hipStreamSynchronize(s));
+      CJS_HIP_TRY(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_bt_clk), sizeof clk));
+      fprintf(stderr, "[cjs huff] last table build of block 0 / wave 0: rank sort %.1f us, allocator pass 1 %.1f, pass 2 %.1f, pass 3 %.1f, lengths back %.1f us\n",
+              (double)(clk[1] - clk[0]) / 100.0, (double)(clk[2] - clk[1]) / 100.0, (double)(clk[3] - clk[2]) / 100.0, (double)(clk[5] - clk[3]) / 100.0, (double)(clk[6] - clk[5]) / 100.0);
+    }
     return 0;
   }
   hipLaunchKernelGGL(huff_block, dim3(nb), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_asz, d_freq, d_alist, dbg ? 1 : 0);
