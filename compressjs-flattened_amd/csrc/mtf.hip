@@ -251,14 +251,16 @@ __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
 // folded into the block's freq[] with atomics; freq is zeroed by the host, the scan kernel adds the end-of-block symbol).
 template <bool WRITE>
 __global__ __launch_bounds__(1024) void mtf_emit_tiles(const uint32_t* __restrict__ blen, MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb) {
-  __shared__ uint32_t freq[258];
+  // symbol counts of the tile: ranks 1-3 and the two run digits make up nearly all symbols, so the counters are kept in eight
+  // copies (by lane) and the digits are summed per wave first -- one LDS atomic per same-address lane is done after the other
+  __shared__ uint32_t freq[WRITE ? 8 * 258 : 1];
   __shared__ uint32_t sm[16];
   const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk], H = mb.nheads[blk];
   const uint32_t base = tile * MT_TILE;
   if (base >= H) { if (!WRITE && threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = 0; return; }
   const uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
   const uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
-  if (WRITE) { for (int i = threadIdx.x; i < 258; i += 1024) freq[i] = 0; __syncthreads(); }
+  if (WRITE) { for (int i = threadIdx.x; i < 8 * 258; i += 1024) freq[i] = 0; __syncthreads(); }
   const uint32_t h0 = base + threadIdx.x * 4;
   uint32_t lit[4], z[4], nd[4], cnt = 0, rk[4];
   // the four heads of a lane: ranks as one 32-bit load, positions as one 128-bit load (+ the next head's position);
@@ -292,16 +294,25 @@ __global__ __launch_bounds__(1024) void mtf_emit_tiles(const uint32_t* __restric
   uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
   uint32_t tot;
   uint32_t o = tcnt[(size_t)blk * tpb + tile] + block_excl_sum<1024>(cnt, sm, tot);
+  uint32_t* rep = freq + (threadIdx.x & 7u) * 258u;
+  uint32_t n1 = 0, n0 = 0;                              // RUNB / RUNA digits of this thread
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    if (lit[j]) { A[o++] = (uint16_t)(rk[j] + 1); atomicAdd(&freq[rk[j] + 1], 1u); }
+    if (lit[j]) { A[o++] = (uint16_t)(rk[j] + 1); atomicAdd(&rep[rk[j] + 1], 1u); }
     const uint32_t v = z[j] + 1u;
     uint32_t nb1 = 0;
     for (uint32_t i = 0; i < nd[j]; i++) { const uint32_t bit = (v >> i) & 1u; A[o++] = (uint16_t)bit; nb1 += bit; }
-    if (nd[j]) { if (nb1) atomicAdd(&freq[1], nb1); if (nd[j] - nb1) atomicAdd(&freq[0], nd[j] - nb1); }
+    n1 += nb1; n0 += nd[j] - nb1;
   }
+  n1 = wave_sum(n1); n0 = wave_sum(n0);
+  if (lane_id() == 0) { if (n1) atomicAdd(&freq[1], n1); if (n0) atomicAdd(&freq[0], n0); }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < 258; i += 1024) if (freq[i]) atomicAdd(&mb.freq[(size_t)blk * 258 + i], freq[i]);
+  for (uint32_t i = threadIdx.x; i < 258; i += 1024) {
+    uint32_t f = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) f += freq[r * 258 + i];
+    if (f) atomicAdd(&mb.freq[(size_t)blk * 258 + i], f);
+  }
 }
 __global__ __launch_bounds__(1024) void mtf_emit_scan(MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb) {
   __shared__ uint32_t sm[16];
