@@ -242,7 +242,19 @@ __device__ void assign_selectors(HuffShared& S, uint32_t* __restrict__ stage /* 
 __device__ void median_split(HuffShared& S, uint8_t* __restrict__ sel, const uint16_t* __restrict__ bcost, uint32_t nsel, int ng) {
   if (threadIdx.x < 8) S.counts[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t g = threadIdx.x; g < nsel; g += 1024) atomicAdd(&S.counts[sel[g]], 1u);
+  {                                                     // groups per table: wave ballots (all groups aim at <= 6 counters)
+    uint32_t c6[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t g0 = 0; g0 < nsel; g0 += 1024) {
+      const uint32_t g = g0 + threadIdx.x;
+      const uint32_t sv = g < nsel ? sel[g] : 255u;
+#pragma unroll
+      for (int j = 0; j < 6; j++) c6[j] += (uint32_t)__popcll(__ballot(sv == (uint32_t)j));
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) if (c6[j]) atomicAdd(&S.counts[j], c6[j]);
+    }
+  }
   S.chist[threadIdx.x] = 0;
   __syncthreads();
   int which = 0;
@@ -611,8 +623,16 @@ __device__ void pack_phase(uint32_t count, F item_fn, uint32_t* words, uint32_t*
     for (uint32_t i = threadIdx.x; i < nwords; i += 1024) words[i] = 0;
     __syncthreads();
     uint64_t b = bit + ex;
+    {                                                   // the thread's items as one or two strings of <= 64 bits: fewer LDS atomics on shared words
+      uint64_t pv = 0; uint32_t pn = 0;
 #pragma unroll
-    for (int j = 0; j < PK_ITEMS; j++) { put_bits(words, word0, b, it[j].val, it[j].nbits); b += it[j].nbits; }
+      for (int j = 0; j < PK_ITEMS; j++) {
+        if (pn + it[j].nbits > 64u) { put_bits(words, word0, b, pv, pn); b += pn; pv = 0; pn = 0; }
+        pv = it[j].nbits >= 64u ? it[j].val : ((pv << it[j].nbits) | (it[j].val & ((1ull << it[j].nbits) - 1ull)));
+        pn += it[j].nbits;
+      }
+      put_bits(words, word0, b, pv, pn);
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nwords; i += 1024) {
       const uint32_t v = __builtin_bswap32(words[i]);
