@@ -25,54 +25,93 @@ namespace cjs {
 constexpr int MTF_CHUNK = CJS_MTF_CHUNK;
 constexpr int MTF_CL_THREADS = CJS_MTF_CL_THREADS;      // workgroup size of mtf_chunk_lists (a multiple of 256)
 
-// ---- A: used-symbol list + run-head compaction.  Tiles of 4096 bytes: count -> per-block scan -> write.
+// ---- A: used-symbol list + run-head compaction.  Tiles of 16 KiB: count (16 bytes per thread: the workgroup scan and its
+// barriers are per tile, at 4 bytes per thread they were most of the kernel: 98 -> 42 us) -> per-block scan -> write.
 // tcnt[blk * tpb + tile] and the used flags (uflag[blk * 258 + byte], zeroed by the host) alias buffers that
 // are not live yet (segkeys, freq).
-constexpr uint32_t MT_TILE = 4096;
-template <bool WRITE>
-__global__ __launch_bounds__(1024) void mtf_head_tiles(const uint8_t* __restrict__ U, uint32_t stride, const uint32_t* __restrict__ blen,
-                                                       MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb, uint32_t* __restrict__ uflag) {
+constexpr uint32_t MT_TILE = 4096;          // heads per tile of the emit kernels
+constexpr uint32_t HT_PER = 16, HT_TILE = 1024 * HT_PER;      // bytes per thread / per tile of the head kernels
+// the heads of bytes p0 .. p0+3 of row u: flag mask, the four bytes; prev = byte p0-1
+__device__ __forceinline__ uint32_t head_flags4(const uint8_t* __restrict__ u, bool row0, uint32_t p0, uint32_t n, uint32_t& mine) {
+  mine = 0;
+  if (p0 >= n) return 0u;
+  // bytes p0-1 .. p0+3 from three aligned 32-bit words (block rows start at odd addresses: the lanes' own 4 bytes straddle
+  // two words); the word before the very first byte of U is not touched
+  const uintptr_t a = (uintptr_t)(u + p0);
+  const uint32_t* al = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+  const uint32_t sh = (uint32_t)(a & 3);
+  const bool first = row0 && p0 == 0;
+  const uint32_t wm = first ? 0u : al[-1], w0 = al[0], w1 = sh ? al[1] : 0u;        // al[1] only when the 4 bytes straddle
+  mine = __builtin_amdgcn_alignbyte(w1, w0, sh);                                   // bytes p0 .. p0+3
+  uint32_t prev = __builtin_amdgcn_alignbyte(w0, wm, sh) >> 24;                      // byte p0-1
+  uint32_t fm = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t p = p0 + j, c = (mine >> (8 * j)) & 0xFFu;
+    if (p < n && (p == 0 || c != prev)) fm |= 1u << j;                              // every used byte value starts a run
+    prev = c;
+  }
+  return fm;
+}
+// count pass: 16 bytes per thread (one workgroup scan per 16 KiB)
+__global__ __launch_bounds__(1024) void mtf_head_count(const uint8_t* __restrict__ U, uint32_t stride, const uint32_t* __restrict__ blen,
+                                                       uint32_t* __restrict__ tcnt, uint32_t tpb, uint32_t* __restrict__ uflag) {
   __shared__ uint32_t used[256];
   __shared__ uint32_t sm[16];
   const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk];
-  const uint32_t base = tile * MT_TILE;
-  if (base >= n) { if (!WRITE && threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = 0; return; }
+  const uint32_t base = tile * HT_TILE;
+  if (base >= n) { if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = 0; return; }
   const uint8_t* u = U + (size_t)blk * stride;
-  if (!WRITE) { if (threadIdx.x < 256) used[threadIdx.x] = 0; __syncthreads(); }
-  const uint32_t p0 = base + threadIdx.x * 4;
-  uint8_t c[4]; uint32_t fm = 0, cnt = 0;
-  uint8_t prev = 0;
+  if (threadIdx.x < 256) used[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t p0 = base + threadIdx.x * HT_PER;
+  uint32_t m4[4] = {0, 0, 0, 0};               // bytes p0 .. p0+15
+  uint32_t prev = 0, cnt = 0;
   if (p0 < n) {
-    // bytes p0-1 .. p0+3 from three aligned 32-bit words (block rows start at odd addresses: the lanes' own 4 bytes straddle
-    // two words); the word before the very first byte of U is not touched
+    // bytes p0-1 .. p0+15 from aligned 32-bit words; the word before the very first byte of U is not touched, the word behind
+    // the sixteen bytes only when they straddle it
     const uintptr_t a = (uintptr_t)(u + p0);
     const uint32_t* al = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3);
     const bool first = blk == 0 && p0 == 0;
-    const uint32_t wm = first ? 0u : al[-1], w0 = al[0], w1 = sh ? al[1] : 0u;        // al[1] only when the 4 bytes straddle
-    const uint32_t mine = __builtin_amdgcn_alignbyte(w1, w0, sh);                     // bytes p0 .. p0+3
-    prev = (uint8_t)(__builtin_amdgcn_alignbyte(w0, wm, sh) >> 24);                   // byte p0-1
-#pragma unroll
-    for (int j = 0; j < 4; j++) c[j] = (uint8_t)(mine >> (8 * j));
+    const uint32_t wm = first ? 0u : al[-1], w0 = al[0], w1 = al[1], w2 = al[2], w3 = al[3], w4 = sh ? al[4] : 0u;
+    m4[0] = __builtin_amdgcn_alignbyte(w1, w0, sh); m4[1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    m4[2] = __builtin_amdgcn_alignbyte(w3, w2, sh); m4[3] = __builtin_amdgcn_alignbyte(w4, w3, sh);
+    prev = __builtin_amdgcn_alignbyte(w0, wm, sh) >> 24;                              // byte p0-1
   }
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < (int)HT_PER; j++) {
     const uint32_t p = p0 + j;
-    if (p >= n) c[j] = 0;
-    if (p < n && (p == 0 || c[j] != prev)) { fm |= 1u << j; cnt++; if (!WRITE) used[c[j]] = 1; }   // every used byte value starts a run
-    prev = c[j];
+    const uint32_t c = p < n ? (m4[j >> 2] >> (8 * (j & 3))) & 0xFFu : 0u;
+    if (p < n && (p == 0 || c != prev)) { cnt++; used[c] = 1; }
+    prev = c;
   }
-  if (!WRITE) {
-    cnt = block_sum<1024>(cnt, sm);                      // (barrier inside: used[] is complete)
-    if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = cnt;
-    if (threadIdx.x < 256 && used[threadIdx.x]) uflag[(size_t)blk * 258 + threadIdx.x] = 1;
-  } else {
-    uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
-    uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
+  const uint32_t tot = block_sum<1024>(cnt, sm);         // (barrier inside: used[] is complete)
+  if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = tot;
+  if (threadIdx.x < 256 && used[threadIdx.x]) uflag[(size_t)blk * 258 + threadIdx.x] = 1;
+}
+// write pass: the same 16 KiB tiles in four rounds of 4 bytes per thread (a thread's stores go to consecutive slots: with
+// sixteen bytes per thread the sixteen conditional stores took 240 us instead of 134)
+__global__ __launch_bounds__(1024) void mtf_head_write(const uint8_t* __restrict__ U, uint32_t stride, const uint32_t* __restrict__ blen,
+                                                       MtfBufs mb, const uint32_t* __restrict__ tcnt, uint32_t tpb) {
+  __shared__ uint32_t sm[16];
+  const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk];
+  const uint32_t base = tile * HT_TILE;
+  if (base >= n) return;
+  const uint8_t* u = U + (size_t)blk * stride;
+  uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
+  uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
+  uint32_t run = tcnt[(size_t)blk * tpb + tile];
+  for (uint32_t r = 0; r < HT_TILE / 4096u; r++) {
+    const uint32_t p0 = base + r * 4096u + threadIdx.x * 4u;
+    if (base + r * 4096u >= n) break;
+    uint32_t mine;
+    const uint32_t fm = head_flags4(u, blk == 0, p0, n, mine);
     uint32_t tot;
-    uint32_t o = tcnt[(size_t)blk * tpb + tile] + block_excl_sum<1024>(cnt, sm, tot);
+    uint32_t o = run + block_excl_sum<1024>((uint32_t)__builtin_popcount(fm), sm, tot);
 #pragma unroll
-    for (int j = 0; j < 4; j++) if ((fm >> j) & 1u) { hpos[o] = p0 + j; hsym[o] = c[j]; o++; }
+    for (int j = 0; j < 4; j++) if ((fm >> j) & 1u) { hpos[o] = p0 + j; hsym[o] = (uint8_t)(mine >> (8 * j)); o++; }
+    run += tot;
   }
 }
 // per block: exclusive scan of the tile counts (tpb <= 1024), number of heads, used-symbol list
@@ -360,9 +399,10 @@ int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const ui
   if (tpb > 1024 || (size_t)tpb > (size_t)w.b.seg_stride * 256) return CJS_E_INVALID_ARG;
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(w.b.segkeys);
   dev_fill(s, w.b.freq, 0, (size_t)nb * 258 * 4);
-  hipLaunchKernelGGL(mtf_head_tiles<false>, dim3(tpb, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b, tcnt, tpb, w.b.freq);
-  hipLaunchKernelGGL(mtf_head_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tpb, w.b.freq);
-  hipLaunchKernelGGL(mtf_head_tiles<true>, dim3(tpb, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b, tcnt, tpb, w.b.freq);
+  const uint32_t tph = (w.stride + HT_TILE - 1) / HT_TILE;           // tiles of the head kernels (<= tpb)
+  hipLaunchKernelGGL(mtf_head_count, dim3(tph, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, tcnt, tph, w.b.freq);
+  hipLaunchKernelGGL(mtf_head_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tph, w.b.freq);
+  hipLaunchKernelGGL(mtf_head_write, dim3(tph, nb), dim3(1024), 0, s, d_U, w.stride, d_blen, w.b, tcnt, tph);
   const uint32_t max_segs = (max_chunks + MTF_SEG - 1) / MTF_SEG;
   hipLaunchKernelGGL(mtf_seg_last, dim3(max_segs, nb), dim3(256), 0, s, w.b);
   hipLaunchKernelGGL(mtf_seg_scan, dim3(nb), dim3(256), 0, s, w.b);
