@@ -286,25 +286,16 @@ __global__ __launch_bounds__(256) void mtf_replay(uint32_t stride, MtfBufs mb) {
   }
 }
 
-// ---- D: RLE2 symbols + histogram.  Tiles of 4096 heads: count -> per-block scan -> write (+ tile histogram
-// folded into the block's freq[] with atomics; freq is zeroed by the host, the scan kernel adds the end-of-block symbol).
-template <bool WRITE>
-__global__ __launch_bounds__(1024) void mtf_emit_tiles(const uint32_t* __restrict__ blen, MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb) {
-  // symbol counts of the tile: ranks 1-3 and the two run digits make up nearly all symbols, so the counters are kept in eight
-  // copies (by lane) and the digits are summed per wave first -- one LDS atomic per same-address lane is done after the other
-  __shared__ uint32_t freq[WRITE ? 8 * 258 : 1];
-  __shared__ uint32_t sm[16];
-  const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk], H = mb.nheads[blk];
-  const uint32_t base = tile * MT_TILE;
-  if (base >= H) { if (!WRITE && threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = 0; return; }
-  const uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
-  const uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
-  if (WRITE) { for (int i = threadIdx.x; i < 8 * 258; i += 1024) freq[i] = 0; __syncthreads(); }
-  const uint32_t h0 = base + threadIdx.x * 4;
-  uint32_t lit[4], z[4], nd[4], cnt = 0, rk[4];
-  // the four heads of a lane: ranks as one 32-bit load, positions as one 128-bit load (+ the next head's position);
-  // rows of hrank / hpos are 16-element aligned and h0 is a multiple of 4
-  uint32_t rk4 = 0, hp[5] = {0, 0, 0, 0, 0};
+// ---- D: RLE2 symbols + histogram.  Tiles of 16 Ki heads: count (four times 4 heads per thread, one workgroup reduction per tile) ->
+// per-block scan -> write (four rounds of 4 heads per thread; + tile histogram folded into the block's freq[] with atomics;
+// freq is zeroed by the host, the scan kernel adds the end-of-block symbol).
+constexpr uint32_t ET_TILE = 4 * MT_TILE;
+// the four heads h0 .. h0+3 (h0 a multiple of 4): literal flag, zero-run length behind the head, its digit count, rank; returns
+// the number of RLE2 symbols they emit.  Ranks as one 32-bit load, positions as one 128-bit load (+ the next head's position):
+// rows of hrank / hpos are 16-element aligned
+__device__ __forceinline__ uint32_t emit_heads4(const uint32_t* __restrict__ hpos, const uint8_t* __restrict__ hrank, uint32_t h0, uint32_t H, uint32_t n,
+                                                uint32_t (&lit)[4], uint32_t (&z)[4], uint32_t (&nd)[4], uint32_t (&rk)[4]) {
+  uint32_t rk4 = 0, hp[5] = {0, 0, 0, 0, 0}, cnt = 0;
   if (h0 < H) {
     rk4 = *reinterpret_cast<const uint32_t*>(hrank + h0);
     const uint4 p4 = *reinterpret_cast<const uint4*>(hpos + h0);
@@ -325,23 +316,54 @@ __global__ __launch_bounds__(1024) void mtf_emit_tiles(const uint32_t* __restric
       cnt += lit[j] + nd[j];
     }
   }
-  if (!WRITE) {
-    cnt = block_sum<1024>(cnt, sm);
-    if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = cnt;
-    return;
+  return cnt;
+}
+__global__ __launch_bounds__(1024) void mtf_emit_count(const uint32_t* __restrict__ blen, MtfBufs mb, uint32_t* __restrict__ tcnt, uint32_t tpb) {
+  __shared__ uint32_t sm[16];
+  const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk], H = mb.nheads[blk];
+  const uint32_t base = tile * ET_TILE;
+  if (base >= H) { if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = 0; return; }
+  const uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
+  const uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < 4; q++) {
+    uint32_t lit[4], z[4], nd[4], rk[4];
+    cnt += emit_heads4(hpos, hrank, base + q * MT_TILE + threadIdx.x * 4u, H, n, lit, z, nd, rk);      // (16 consecutive heads per thread: 78 us, the loads of a wave 64 B apart)
   }
+  cnt = block_sum<1024>(cnt, sm);
+  if (threadIdx.x == 0) tcnt[(size_t)blk * tpb + tile] = cnt;
+}
+__global__ __launch_bounds__(1024) void mtf_emit_write(const uint32_t* __restrict__ blen, MtfBufs mb, const uint32_t* __restrict__ tcnt, uint32_t tpb) {
+  // symbol counts of the tile: ranks 1-3 and the two run digits make up nearly all symbols, so the counters are kept in eight
+  // copies (by lane) and the digits are summed per wave first -- one LDS atomic per same-address lane is done after the other
+  __shared__ uint32_t freq[8 * 258];
+  __shared__ uint32_t sm[16];
+  const uint32_t blk = blockIdx.y, tile = blockIdx.x, n = blen[blk], H = mb.nheads[blk];
+  const uint32_t base = tile * ET_TILE;
+  if (base >= H) return;
+  const uint32_t* hpos = mb.hpos + (size_t)blk * mb.hstride;
+  const uint8_t* hrank = mb.hrank + (size_t)blk * mb.hstride;
+  for (int i = threadIdx.x; i < 8 * 258; i += 1024) freq[i] = 0;
+  __syncthreads();
   uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
-  uint32_t tot;
-  uint32_t o = tcnt[(size_t)blk * tpb + tile] + block_excl_sum<1024>(cnt, sm, tot);
   uint32_t* rep = freq + (threadIdx.x & 7u) * 258u;
   uint32_t n1 = 0, n0 = 0;                              // RUNB / RUNA digits of this thread
+  uint32_t run = tcnt[(size_t)blk * tpb + tile];
+  for (uint32_t r = 0; r < ET_TILE / MT_TILE && base + r * MT_TILE < H; r++) {
+    uint32_t lit[4], z[4], nd[4], rk[4];
+    const uint32_t cnt = emit_heads4(hpos, hrank, base + r * MT_TILE + threadIdx.x * 4u, H, n, lit, z, nd, rk);
+    uint32_t tot;
+    uint32_t o = run + block_excl_sum<1024>(cnt, sm, tot);
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (lit[j]) { A[o++] = (uint16_t)(rk[j] + 1); atomicAdd(&rep[rk[j] + 1], 1u); }
-    const uint32_t v = z[j] + 1u;
-    uint32_t nb1 = 0;
-    for (uint32_t i = 0; i < nd[j]; i++) { const uint32_t bit = (v >> i) & 1u; A[o++] = (uint16_t)bit; nb1 += bit; }
-    n1 += nb1; n0 += nd[j] - nb1;
+    for (int j = 0; j < 4; j++) {
+      if (lit[j]) { A[o++] = (uint16_t)(rk[j] + 1); atomicAdd(&rep[rk[j] + 1], 1u); }
+      const uint32_t v = z[j] + 1u;
+      uint32_t nb1 = 0;
+      for (uint32_t i = 0; i < nd[j]; i++) { const uint32_t bit = (v >> i) & 1u; A[o++] = (uint16_t)bit; nb1 += bit; }
+      n1 += nb1; n0 += nd[j] - nb1;
+    }
+    run += tot;
   }
   n1 = wave_sum(n1); n0 = wave_sum(n0);
   if (lane_id() == 0) { if (n1) atomicAdd(&freq[1], n1); if (n0) atomicAdd(&freq[0], n0); }
@@ -409,9 +431,10 @@ int mtf_run(hipStream_t s, MtfWork& w, const uint8_t* d_U, uint32_t nb, const ui
   hipLaunchKernelGGL(mtf_chunk_lists, dim3(max_segs, nb), dim3(MTF_CL_THREADS), 0, s, w.b);
   hipLaunchKernelGGL(mtf_replay, dim3((max_chunks + 255) / 256, nb), dim3(256), 0, s, w.stride, w.b);
   dev_fill(s, w.b.freq, 0, (size_t)nb * 258 * 4);
-  hipLaunchKernelGGL(mtf_emit_tiles<false>, dim3(tpb, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpb);
-  hipLaunchKernelGGL(mtf_emit_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tpb);
-  hipLaunchKernelGGL(mtf_emit_tiles<true>, dim3(tpb, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpb);
+  const uint32_t tpe = (w.stride + ET_TILE - 1) / ET_TILE;           // tiles of the emit kernels
+  hipLaunchKernelGGL(mtf_emit_count, dim3(tpe, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpe);
+  hipLaunchKernelGGL(mtf_emit_scan, dim3(nb), dim3(1024), 0, s, w.b, tcnt, tpe);
+  hipLaunchKernelGGL(mtf_emit_write, dim3(tpe, nb), dim3(1024), 0, s, d_blen, w.b, tcnt, tpe);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
 }
