@@ -466,38 +466,30 @@ __global__ __launch_bounds__(256) void bwt_flags(const uint64_t* __restrict__ ke
   }
 }
 
-// single workgroup: exclusive sums of [0],[1]; exclusive prefix-max of [2]; totals -> counters[0..1].  Eight consecutive tiles
-// per thread (the host waits for this kernel every round: with one tile per thread its 24 rounds of three workgroup scans took
-// 44 us for the 24 K tiles of round 1)
+// single workgroup: exclusive sums of [0],[1]; exclusive prefix-max of [2]; totals -> counters[0..1]
+// (eight consecutive tiles per thread, one round of workgroup scans per 8 K tiles: 78 instead of 44 us for the 24 K tiles of
+// round 1 -- the strided accesses cost more than the barriers saved)
 __global__ __launch_bounds__(1024) void bwt_scan_tiles(uint32_t* __restrict__ tile_cnt, uint32_t T, uint32_t* __restrict__ counters,
                                                       uint32_t* __restrict__ host_mirror /* pinned host memory, read after the stream sync */) {
   __shared__ uint32_t sm[16];
   __shared__ uint32_t mx[1024];
-  constexpr uint32_t K = 8;
   uint32_t c0 = 0, c1 = 0, cm = 0;
-  for (uint32_t base = 0; base < T; base += 1024 * K) {
-    const uint32_t i0 = base + threadIdx.x * K;
-    uint32_t v0[K], v1[K], v2[K], s0 = 0, s1 = 0, m2 = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < K; k++) {
-      const bool ok = i0 + k < T;
-      v0[k] = ok ? tile_cnt[i0 + k] : 0u; v1[k] = ok ? tile_cnt[T + i0 + k] : 0u; v2[k] = ok ? tile_cnt[2 * (size_t)T + i0 + k] : 0u;
-      s0 += v0[k]; s1 += v1[k]; m2 = v2[k] > m2 ? v2[k] : m2;
-    }
+  for (uint32_t base = 0; base < T; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const bool ok = i < T;
     uint32_t t0, t1;
-    const uint32_t e0 = block_excl_sum<1024>(s0, sm, t0);
-    const uint32_t e1 = block_excl_sum<1024>(s1, sm, t1);
-    const uint32_t im = block_incl_max<1024>(m2, sm);
+    const uint32_t v0 = ok ? tile_cnt[i] : 0u, v1 = ok ? tile_cnt[T + i] : 0u, v2 = ok ? tile_cnt[2 * (size_t)T + i] : 0u;
+    const uint32_t e0 = block_excl_sum<1024>(v0, sm, t0);
+    const uint32_t e1 = block_excl_sum<1024>(v1, sm, t1);
+    const uint32_t im = block_incl_max<1024>(v2, sm);
     mx[threadIdx.x] = im;
     __syncthreads();
     const uint32_t prev = threadIdx.x ? mx[threadIdx.x - 1] : 0u;
     const uint32_t chunk_max = mx[1023];
     __syncthreads();
-    uint32_t r0 = c0 + e0, r1 = c1 + e1, rm = prev > cm ? prev : cm;
-#pragma unroll
-    for (uint32_t k = 0; k < K; k++) {
-      if (i0 + k < T) { tile_cnt[i0 + k] = r0; tile_cnt[T + i0 + k] = r1; tile_cnt[2 * (size_t)T + i0 + k] = rm; }
-      r0 += v0[k]; r1 += v1[k]; rm = v2[k] > rm ? v2[k] : rm;
+    if (ok) {
+      tile_cnt[i] = c0 + e0; tile_cnt[T + i] = c1 + e1;
+      tile_cnt[2 * (size_t)T + i] = prev > cm ? prev : cm;
     }
     c0 += t0; c1 += t1; cm = chunk_max > cm ? chunk_max : cm;
   }
