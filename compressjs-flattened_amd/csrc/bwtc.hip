@@ -383,6 +383,7 @@ struct HostCoder {
   static constexpr uint32_t RING = 8, RCAP = 1u << 15;
   std::vector<uint64_t> ring[RING];
   uint32_t ring_n[RING];
+  int ring_cpu[RING];
   std::thread low_thread;
   // the two threads of the split mode write their own state at every step: each side on cache lines of its own (with range
   // and low on one line the pair ran 8x slower than one thread)
@@ -401,6 +402,9 @@ struct HostCoder {
   uint64_t dbg_full_spins = 0;                          // range side: polls while the ring was full (CJS_DEBUG)
   alignas(128) uint64_t dbg_empty_spins = 0;            // low side: polls while the ring was empty
   int dbg_low_cpu[2] = {-1, -1};
+  int near_cpu = -1;                                    // low side: the cpu the range side was last seen on
+  cpu_set_t allowed;                                    // the caller's affinity when the split started
+  bool have_allowed = false;
   explicit HostCoder(std::vector<uint8_t>& o) : out(o) { len = o.size(); reserve(4096); }
   ~HostCoder() { stop_thread(); }
   void reserve(size_t extra) {                          // room for `extra` more bytes (a coder step emits at most 3)
@@ -436,6 +440,8 @@ struct HostCoder {
   void start_split() {
     for (auto& r : ring) r.assign(RCAP, 0ull);
     cur = ring[0].data(); cur_n = 0; split = true;
+    have_allowed = sched_getaffinity(0, sizeof allowed, &allowed) == 0;
+    near_cpu = sched_getcpu();
     low_thread = std::thread([this] { low_loop(); });
     keep_off_my_core(low_thread);
   }
@@ -468,13 +474,13 @@ struct HostCoder {
     }
     return n > 0;
   }
-  static void keep_off_my_core(std::thread& t) {
+  void keep_off_my_core(std::thread& t) { place_near(t.native_handle(), sched_getcpu()); }
+  void place_near(pthread_t th, int cpu) {        // th: the low thread; cpu: where the range side runs
     static const bool off = getenv("CJS_BWTC_NO_AFFINITY") != nullptr;
-    const int cpu = sched_getcpu();
     if (off || cpu < 0) return;
-    cpu_set_t mine, near, allowed;
+    cpu_set_t mine, near;
     if (!read_cpu_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu, &mine)) return;
-    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    if (!have_allowed) return;
     const char* domains[2] = {"/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", "/sys/devices/system/cpu/cpu%d/topology/package_cpus_list"};
     for (const char* d : domains) {
       if (!read_cpu_list(d, cpu, &near)) continue;
@@ -482,7 +488,7 @@ struct HostCoder {
       CPU_ZERO(&want);
       int left = 0;
       for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &near) && CPU_ISSET(c, &allowed) && !CPU_ISSET(c, &mine)) { CPU_SET(c, &want); left++; }
-      if (left > 0) { (void)pthread_setaffinity_np(t.native_handle(), sizeof want, &want); return; }
+      if (left > 0) { (void)pthread_setaffinity_np(th, sizeof want, &want); return; }
     }
   }
   inline uint32_t shifts_needed() {                     // (zero or one shift is a coin flip per step: no branch for it)
@@ -498,6 +504,7 @@ struct HostCoder {
   void hand_over() {                                    // the full (or last) buffer goes to the low thread
     const uint64_t p = produced.load(std::memory_order_relaxed);
     ring_n[p % RING] = cur_n;
+    ring_cpu[p % RING] = sched_getcpu();                 // (the low thread follows this thread when the scheduler moves it)
     produced.store(p + 1, std::memory_order_release);
     while (p + 1 - consumed.load(std::memory_order_acquire) >= RING) { __builtin_ia32_pause(); dbg_full_spins++; }
     cur = ring[(p + 1) % RING].data(); cur_n = 0;
@@ -517,6 +524,7 @@ struct HostCoder {
       }
       const uint64_t* rec = ring[c % RING].data();
       uint32_t n = ring_n[c % RING];
+      if (ring_cpu[c % RING] != near_cpu) { near_cpu = ring_cpu[c % RING]; if (c) place_near(pthread_self(), near_cpu); }      // the range side moved
       if (!failed.load(std::memory_order_relaxed)) {
         try { reserve(4 * (size_t)n + help + 64); } catch (...) { failed.store(true, std::memory_order_relaxed); }
       }
