@@ -138,17 +138,21 @@ __global__ __launch_bounds__(1024) void mtf_head_scan(MtfBufs mb, uint32_t* __re
 //   mtf_chunk_lists: per segment, walk its 32 chunks: rank-by-counting over the <=256 keys, then fold the chunk in
 constexpr int MTF_SEG = 32;     // chunks per segment
 __global__ __launch_bounds__(256) void mtf_seg_last(MtfBufs mb) {
-  __shared__ int last[256];
+  __shared__ int last[4][256];           // four copies by lane: a few symbols carry most heads (same-address LDS atomics are serial)
   const uint32_t blk = blockIdx.y, seg = blockIdx.x, H = mb.nheads[blk];
   const uint32_t h0 = seg * MTF_SEG * MTF_CHUNK;
   if (h0 >= H) return;
   const uint32_t h1 = h0 + MTF_SEG * MTF_CHUNK < H ? h0 + MTF_SEG * MTF_CHUNK : H;
   const uint8_t* hsym = mb.hsym + (size_t)blk * mb.hstride;
-  last[threadIdx.x] = -1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) last[r][threadIdx.x] = -1;
   __syncthreads();
-  for (uint32_t h = h0 + threadIdx.x; h < h1; h += 256) atomicMax(&last[hsym[h]], (int)h);
+  int* mine = last[threadIdx.x & 3];
+  for (uint32_t h = h0 + threadIdx.x; h < h1; h += 256) atomicMax(&mine[hsym[h]], (int)h);
   __syncthreads();
-  mb.segkeys[((size_t)blk * mb.seg_stride + seg) * 256 + threadIdx.x] = last[threadIdx.x];
+  const int a01 = last[0][threadIdx.x] > last[1][threadIdx.x] ? last[0][threadIdx.x] : last[1][threadIdx.x];
+  const int a23 = last[2][threadIdx.x] > last[3][threadIdx.x] ? last[2][threadIdx.x] : last[3][threadIdx.x];
+  mb.segkeys[((size_t)blk * mb.seg_stride + seg) * 256 + threadIdx.x] = a01 > a23 ? a01 : a23;
 }
 __global__ __launch_bounds__(256) void mtf_seg_scan(MtfBufs mb) {
   __shared__ uint32_t used[256];

@@ -5,7 +5,7 @@ k=$1; shift
 i=0
 for e in "$@"; do
   i=$((i+1))
-  env $e timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/dbg_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > gpurun_out/dbg_$i.log 2>&1
+  rm -rf gpurun_out/dbg_$i; env $e timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/dbg_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > gpurun_out/dbg_$i.log 2>&1
   python3 - "$(ls gpurun_out/dbg_$i/*/*kernel_trace.csv)" "$k" "$e" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
