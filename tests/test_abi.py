@@ -65,6 +65,23 @@ def test_no_cpu_fallback_without_a_device():
     assert e.value.errorCode == -30          # CJS_E_NO_DEVICE: the product never routes through a CPU path
 
 
+def test_free_and_trim_need_no_device():
+    # cjs_free takes what the library handed out (plain malloc or a pinned result buffer) and, like free(), a null pointer;
+    # memory it does not know is plain malloc'd memory.  cjs_trim with nothing cached is a no-op.  Neither needs a GPU.
+    lib = ctypes.CDLL(LIB)
+    lib.cjs_free.argtypes = [ctypes.c_void_p]
+    lib.cjs_free.restype = None
+    lib.cjs_free(None)
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    p = libc.malloc(4096)
+    assert p
+    lib.cjs_free(ctypes.c_void_p(p))
+    lib.cjs_trim.restype = None
+    lib.cjs_trim()
+
+
 def test_product_does_not_link_the_oracle():
     out = subprocess.run(["nm", "-D", LIB], capture_output=True, text=True).stdout
     assert "cjs_oracle" not in out
