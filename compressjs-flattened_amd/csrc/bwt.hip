@@ -156,8 +156,11 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
 
 // The same counts from a byte per key: the scatter pass in front left the NEXT digit of every key it moved in dig[] (same
 // index as the key), so this pass reads 1 B per key instead of 8.  Aligned 32-bit loads over the tile's byte range.
+// With delta > 0 the bytes are the block TEXT (cyclic form): the first pass's digit of the suffix at position p is the text byte
+// at p + delta, so a tile's digits are the text bytes [off + delta, off + delta + nvalid) of its block -- no keys are built for
+// the count (rs_hist<GEN>: 130 us); the one tile per block whose range wraps around the block end counts byte by byte.
 template <int HB>       // histogram copies per wave (the zeroing and folding of 4 * 256 * HB counters is most of this kernel's LDS traffic)
-__global__ __launch_bounds__(256) void rs_hist_bytes(const uint8_t* __restrict__ dig, SegGeom sg, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void rs_hist_bytes(const uint8_t* __restrict__ dig, SegGeom sg, uint32_t* __restrict__ hist, uint32_t delta) {
   __shared__ uint32_t h[4 * 256 * HB];
   const int tid = threadIdx.x;
   uint32_t* hw = h + (tid >> 6) * 256 * HB + (tid & (HB - 1));
@@ -165,7 +168,14 @@ __global__ __launch_bounds__(256) void rs_hist_bytes(const uint8_t* __restrict__
   for (int i = 0; i < 4 * HB; i++) h[i * 256 + tid] = 0;
   const uint32_t tile = blockIdx.x;
   const TileRef t = tile_ref(sg, tile);
-  const uintptr_t a0 = (uintptr_t)(dig + t.base), a1 = a0 + t.nvalid;
+  const uint32_t sn = t.seg + 1 == sg.nseg ? sg.n_last : sg.stride;
+  const bool wraps = delta && t.nvalid && t.off + delta + t.nvalid > sn;         // (wave-uniform)
+  if (wraps) {
+    __syncthreads();
+    const uint8_t* tx = dig + (size_t)t.seg * sg.stride;
+    for (uint32_t e = tid; e < t.nvalid; e += 256) atomicAdd(&hw[(uint32_t)tx[(t.off + e + delta) % sn] * HB], 1u);
+  }
+  const uintptr_t a0 = (uintptr_t)(dig + t.base + delta), a1 = a0 + (wraps ? 0u : t.nvalid);
   const uint32_t* al = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
   uint32_t wv[5];
 #pragma unroll
@@ -1405,16 +1415,19 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
   if (T > w.hist_tiles || sg.nseg > w.bintot_segs) return CJS_E_INVALID_ARG;
   K* kk[2] = {k0, k1}; uint32_t* vv[2] = {v0, v1};
   const GenSrc g0{nullptr, 0, 0, 0};
+  static const bool env_text_hist = getenv("CJS_R1_TEXT_HIST") == nullptr || atoi(getenv("CJS_R1_TEXT_HIST")) != 0;
   for (int shift = lo_bit; shift < hi_bit; shift += 8) {
     const bool first_gen = gen && shift == lo_bit;        // the first pass makes its keys from the block bytes
     const bool dig_out = dig && shift + 8 < hi_bit;          // a pass follows: leave its digits
     if (first_hist_ready && shift == lo_bit) {}
     else if (dig && shift != lo_bit) {
       static const int hb = getenv("CJS_HB_HR") ? atoi(getenv("CJS_HB_HR")) : 4;      // 100 M keys: 59-82 us per pass with 4 copies, 72-85 with 8, 75-130 with 2
-      if (hb == 2) hipLaunchKernelGGL(rs_hist_bytes<2>, dim3(T), dim3(256), 0, s, dig, sg, w.hist);
-      else if (hb == 4) hipLaunchKernelGGL(rs_hist_bytes<4>, dim3(T), dim3(256), 0, s, dig, sg, w.hist);
-      else hipLaunchKernelGGL(rs_hist_bytes<8>, dim3(T), dim3(256), 0, s, dig, sg, w.hist);
+      if (hb == 2) hipLaunchKernelGGL(rs_hist_bytes<2>, dim3(T), dim3(256), 0, s, dig, sg, w.hist, 0u);
+      else if (hb == 4) hipLaunchKernelGGL(rs_hist_bytes<4>, dim3(T), dim3(256), 0, s, dig, sg, w.hist, 0u);
+      else hipLaunchKernelGGL(rs_hist_bytes<8>, dim3(T), dim3(256), 0, s, dig, sg, w.hist, 0u);
     }
+    else if (first_gen && gen->cyclic && gen->packed && shift == PK_KEY_LO && env_text_hist)       // packed cyclic sort: the first digit is a text byte
+      hipLaunchKernelGGL(rs_hist_bytes<4>, dim3(T), dim3(256), 0, s, gen->T, sg, w.hist, gen->packed == 2 ? 6u : 4u);
     else if (first_gen) hipLaunchKernelGGL((rs_hist<K, true>), dim3(T), dim3(256), 0, s, kk[cur], sg, *gen, shift, w.hist, T);
     else hipLaunchKernelGGL((rs_hist<K, false>), dim3(T), dim3(256), 0, s, kk[cur], sg, g0, shift, w.hist, T);
     if (sg.tps <= 4 * SB_CHUNK) hipLaunchKernelGGL(rs_scan_bins, dim3(sg.nseg), dim3(256), 0, s, w.hist, sg.tps, w.bintot);

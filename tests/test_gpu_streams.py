@@ -338,7 +338,7 @@ def _run_variant(env, n, seed, level):
                                  {"CJS_APPLY_HALVES": "3"}, {"CJS_APPLY_HALVES": "2"},
                                  {"CJS_FUSE_GATHER": "0"}, {"CJS_FUSE_GATHER": "0", "CJS_TILE_SORT": "radix"}, {"CJS_FUSE_GATHER": "1", "CJS_TILE_SORT": "count"},
                                  {"CJS_R1_PACKED": "1", "CJS_APPLY_HALVES": "2", "CJS_TILE_SORT": "radix"},
-                                 {"CJS_DIRECT_EMIT": "0"}, {"CJS_R1_DIG": "0"}, {"CJS_HB_HR": "2"}, {"CJS_HB_HR": "8"}, {"CJS_BIG_GROUP_TEST": "0"},
+                                 {"CJS_DIRECT_EMIT": "0"}, {"CJS_R1_DIG": "0"}, {"CJS_R1_TEXT_HIST": "0"}, {"CJS_HB_HR": "2"}, {"CJS_HB_HR": "8"}, {"CJS_BIG_GROUP_TEST": "0"},
                                  {"CJS_HUFF_SPLIT": "1"}, {"CJS_HUFF_SPLIT": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_suffix_sort_variants_are_bit_exact(oracle, env):
