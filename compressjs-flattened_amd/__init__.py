@@ -35,6 +35,12 @@ class Stats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class ShardMeta(ctypes.Structure):
+    """cjs_shard_meta: what the ranks of a multi-GPU job exchange between the block phase and the pack phase (32 bytes)."""
+    _fields_ = [("bits", ctypes.c_uint64), ("total_blocks", ctypes.c_uint64), ("first_block", ctypes.c_uint64),
+                ("blocks", ctypes.c_uint32), ("crc_fold", ctypes.c_uint32)]
+
+
 _lib = None
 
 
@@ -74,6 +80,11 @@ def load_library():
     L.cjs_bzip2_compress_device.argtypes = [V, V, S, I, V, S, PS, ctypes.POINTER(Stats)]
     L.cjs_bzip2_compress_device_range.argtypes = [V, V, S, I, ctypes.c_long, ctypes.c_long, V, S, ctypes.POINTER(ctypes.c_uint64),
                                                   V, ctypes.c_long, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(Stats)]
+    L.cjs_bzip2_shard_share_bytes.argtypes = [S, I]
+    L.cjs_bzip2_shard_share_bytes.restype = S
+    L.cjs_bzip2_shard_tiles.argtypes = [V, V, S, I, I, V]
+    L.cjs_bzip2_shard_blocks.argtypes = [V, V, S, I, I, I, V, ctypes.POINTER(ShardMeta), ctypes.POINTER(Stats)]
+    L.cjs_bzip2_shard_pack.argtypes = [V, I, I, I, ctypes.POINTER(ShardMeta), V, S, PS, PS, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
     return L
 
@@ -197,6 +208,29 @@ class DeviceContext:
                                                       ctypes.byref(bits), crcs.ctypes.data, crc_cap, ctypes.byref(total),
                                                       ctypes.byref(stats) if stats is not None else None))
         return bits.value, total.value, crcs[: total.value]
+
+
+    # ---- the three phases of a one-process-per-GPU job (include/cjs_hip.h); the caller owns the exchange between them
+    def share_bytes(self, n, world):
+        return self.L.cjs_bzip2_shard_share_bytes(n, world)
+
+    def shard_tiles(self, d_in_ptr, n, rank, world, d_share_ptr):
+        _check(self.L.cjs_bzip2_shard_tiles(self.h, d_in_ptr, n, rank, world, d_share_ptr))
+
+    def shard_blocks(self, d_in_ptr, n, rank, world, d_shares_ptr, stats=None):
+        meta = ShardMeta()
+        _check(self.L.cjs_bzip2_shard_blocks(self.h, d_in_ptr, n, self.level, rank, world, d_shares_ptr, ctypes.byref(meta),
+                                             ctypes.byref(stats) if stats is not None else None))
+        return meta
+
+    def shard_pack(self, rank, metas, d_out_ptr, out_cap):
+        """-> (frag_off, frag_len, stream_off, stream_len): bytes [frag_off, +frag_len) of d_out are stream bytes [stream_off, +frag_len)"""
+        arr = (ShardMeta * len(metas))(*metas)
+        fo, fl = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        so, sl = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self.L.cjs_bzip2_shard_pack(self.h, self.level, rank, len(metas), arr, d_out_ptr, out_cap, ctypes.byref(fo), ctypes.byref(fl),
+                                           ctypes.byref(so), ctypes.byref(sl)))
+        return fo.value, fl.value, so.value, sl.value
 
 
 def trim():

@@ -1527,7 +1527,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   const Geom g{nb, stride, n_last};
   const uint32_t max_n = nb > 1 ? stride : n_last;
   const int grid_lin = (int)((M + 255) / 256 < 65535u * 16u ? (M + 255) / 256 : 65535u * 16u);
-  LaunchTimes& lt = w.lt; lt.reset(); lt.enabled = stats != nullptr;
+  LaunchTimes& lt = w.lt; lt.reset(); lt.enabled = stats != nullptr; lt.min_elems = M;      // the roofline is priced on the full-size scatter passes
 
   int c = 0, pc = 0;        // current key/val buffer, current pos buffer
   dev_fill(s, w.counters, 0, 64);

@@ -99,14 +99,17 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
   hipEvent_t ev[2 * MAXP];
   uint64_t elems[MAXP];
   int n = 0, made = 0;
-  bool enabled = false;
+  bool enabled = false, open = false;
+  uint64_t min_elems = 0;          // only launches over at least this many elements are timed (the full-size passes of a sort)
   void begin(hipStream_t s, uint64_t e) {
-    if (!enabled || n >= MAXP) return;
-    while (made < 2 * (n + 1)) { if (hipEventCreate(&ev[made]) != hipSuccess) { enabled = false; return; } made++; }
+    open = false;
+    if (!enabled || n >= MAXP || e < min_elems) return;
+    open = true;
+    while (made < 2 * (n + 1)) { if (hipEventCreate(&ev[made]) != hipSuccess) { enabled = false; open = false; return; } made++; }
     elems[n] = e;
     (void)hipEventRecord(ev[2 * n], s);
   }
-  void end(hipStream_t s) { if (!enabled || n >= MAXP) return; (void)hipEventRecord(ev[2 * n + 1], s); n++; }
+  void end(hipStream_t s) { if (!enabled || !open || n >= MAXP) return; (void)hipEventRecord(ev[2 * n + 1], s); n++; open = false; }
   void resolve(cjs_stats* st) {
     double ms = 0; uint64_t e = 0;
     for (int i = 0; i < n; i++) { float t = 0; if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { ms += t; e += elems[i]; } }

@@ -32,11 +32,14 @@ struct HuffWork {
 
 int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                     const uint32_t* d_asz, const uint32_t* d_freq, const uint8_t* d_alist);
+// a rank of a multi-GPU job: the stream CRC folded over ALL ranks' blocks (the trailer writer needs it), and whether the next
+// rank's blocks follow this fragment (pack_frame then completes the fragment's last word with the leading bits of the block magic)
+struct PackShard { uint32_t stream_crc; int follow_magic; };
 // Packs blocks [first, first+count) starting at absolute bit `start_bit` of d_out32 (the part the stream occupies is
 // zeroed here, the bits in front of start_bit included).
 int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first, uint32_t count, uint64_t start_bit, int level,
                   int write_header, int write_trailer, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                   const uint32_t* d_asz, const uint8_t* d_alist, const uint32_t* d_block_crc, const uint32_t* d_pidx,
-                  uint32_t* d_out32, size_t out_cap_bytes);    // scalars[2] = 1 and nothing written if the stream does not fit
+                  uint32_t* d_out32, size_t out_cap_bytes, const PackShard* ps = nullptr);    // scalars[2] = 1 and nothing written if the stream does not fit
 
 }  // namespace cjs

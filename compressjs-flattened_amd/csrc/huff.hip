@@ -561,15 +561,15 @@ __global__ __launch_bounds__(1024) void hs_finish(HuffBufs hb, const uint32_t* _
 // also the output size check (no host round trip for it): too_small[0] = 1 stops the pack kernels before they write anything
 __global__ void huff_offsets(HuffBufs hb, const uint32_t* __restrict__ block_crc, uint32_t nb, uint32_t first, uint32_t count,
                              uint64_t start_bit, uint32_t* __restrict__ stream_crc_out, uint64_t trailer_bits, uint64_t cap_bytes,
-                             uint64_t* __restrict__ too_small) {
+                             uint64_t* __restrict__ too_small, int crc_given, uint32_t crc_value) {
   if (threadIdx.x || blockIdx.x) return;
   (void)first;
   uint64_t bit = start_bit;                         // per-block buffers are indexed relative to `first`
   for (uint32_t k = 0; k < count; k++) { hb.bitoff[k] = bit; bit += hb.bitlen[k]; }
   hb.bitoff[count] = bit;
   too_small[0] = (bit + trailer_bits + 7) / 8 + 8 > cap_bytes ? 1u : 0u;
-  uint32_t c = 0;
-  for (uint32_t k = 0; k < nb; k++) c = ((c << 1) | (c >> 31)) ^ block_crc[k];      // Bzip2:2237
+  uint32_t c = crc_value;                           // (a rank of a multi-GPU job is handed the fold over all ranks' blocks)
+  if (!crc_given) { c = 0; for (uint32_t k = 0; k < nb; k++) c = ((c << 1) | (c >> 31)) ^ block_crc[k]; }      // Bzip2:2237
   *stream_crc_out = c;
 }
 
@@ -726,12 +726,19 @@ __global__ __launch_bounds__(1024) void pack_data(HuffBufs hb, const uint16_t* _
 }
 
 // stream header / trailer.  One lane.
-__global__ void pack_frame(HuffBufs hb, uint32_t nb_range_end, int level, int write_header, int write_trailer,
+// follow_magic: the blocks of the next rank of a multi-GPU job follow this fragment: the last word of the fragment is completed
+// with the leading bits of what comes next in the stream -- always the 48-bit block magic -- so that the ranks' fragments are
+// disjoint runs of whole 32-bit words of the one stream (the next rank leaves its first, partial word out of its fragment).
+__global__ void pack_frame(HuffBufs hb, uint32_t nb_range_end, int level, int write_header, int write_trailer, int follow_magic,
                            const uint32_t* __restrict__ stream_crc, uint32_t* __restrict__ out32, uint64_t* __restrict__ total_bits) {
   if (threadIdx.x || blockIdx.x) return;
   if (total_bits[2]) { total_bits[0] = hb.bitoff[nb_range_end] + (write_trailer ? 80u : 0u); return; }      // output too small: nothing is written
   if (write_header) atomicOr(&out32[0], __builtin_bswap32(0x425a6830u + (uint32_t)level));   // 'B''Z''h''0'+level
   uint64_t bit = hb.bitoff[nb_range_end];
+  if (follow_magic && !write_trailer && (bit & 31)) {
+    const uint32_t room = 32 - (uint32_t)(bit & 31);
+    atomicOr(&out32[bit >> 5], __builtin_bswap32((uint32_t)(0x314159265359ull >> (48 - room))));
+  }
   if (write_trailer) {
     const uint64_t vals[2] = {0x177245385090ull, (uint64_t)*stream_crc};
     const uint32_t nbs[2] = {48, 32};
@@ -821,16 +828,16 @@ int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A
 int huff_pack_run(hipStream_t s, HuffWork& w, uint32_t nb_total, uint32_t first, uint32_t count, uint64_t start_bit, int level,
                   int write_header, int write_trailer, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,
                   const uint32_t* d_asz, const uint8_t* d_alist, const uint32_t* d_block_crc, const uint32_t* d_pidx,
-                  uint32_t* d_out32, size_t out_cap_bytes) {
+                  uint32_t* d_out32, size_t out_cap_bytes, const PackShard* ps) {
   uint32_t* stream_crc = (uint32_t*)(w.scalars + 1);
   hipLaunchKernelGGL(huff_offsets, dim3(1), dim3(1), 0, s, w.b, d_block_crc, nb_total, first, count, start_bit, stream_crc,
-                     (uint64_t)(write_trailer ? 80 : 0), (uint64_t)out_cap_bytes, w.scalars + 2);
+                     (uint64_t)(write_trailer ? 80 : 0), (uint64_t)out_cap_bytes, w.scalars + 2, ps ? 1 : 0, ps ? ps->stream_crc : 0u);
   hipLaunchKernelGGL(pack_zero_output, dim3(4096), dim3(256), 0, s, w.b, count, (uint64_t)(write_trailer ? 80 : 0), d_out32, (uint64_t)out_cap_bytes, w.scalars + 2);
   if (count) {
     hipLaunchKernelGGL(pack_block, dim3(count), dim3(1024), 0, s, w.b, first, d_A, a_stride, d_npos, d_asz, d_alist, d_block_crc, d_pidx, d_out32, w.scalars + 2);
     hipLaunchKernelGGL(pack_data, dim3((unsigned)(w.b.tile_stride - 1), count), dim3(1024), 0, s, w.b, d_A, a_stride, d_npos, d_out32, w.scalars + 2);
   }
-  hipLaunchKernelGGL(pack_frame, dim3(1), dim3(1), 0, s, w.b, count, level, write_header, write_trailer, stream_crc, d_out32, w.scalars);
+  hipLaunchKernelGGL(pack_frame, dim3(1), dim3(1), 0, s, w.b, count, level, write_header, write_trailer, ps ? ps->follow_magic : 0, stream_crc, d_out32, w.scalars);
   CJS_HIP_TRY(hipGetLastError());
   return 0;
 }

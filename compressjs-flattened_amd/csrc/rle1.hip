@@ -74,9 +74,10 @@ __device__ __forceinline__ void run_starts(const uint8_t* __restrict__ in, uint6
 }
 
 // ---- P1: per tile first / last boundary (global position + 1; 0 = none)
-__global__ __launch_bounds__(256) void rle_tile_summary(const uint8_t* __restrict__ in, uint64_t N, uint64_t* __restrict__ fb, uint64_t* __restrict__ lb) {
+__global__ __launch_bounds__(256) void rle_tile_summary(const uint8_t* __restrict__ in, uint64_t N, uint64_t* __restrict__ fb, uint64_t* __restrict__ lb, uint32_t t0) {
   __shared__ uint32_t smin[4], smax[4];
-  const uint64_t tile_start = (uint64_t)blockIdx.x * RT, p0 = tile_start + (uint64_t)threadIdx.x * 16;
+  const uint32_t tile = t0 + blockIdx.x;
+  const uint64_t tile_start = (uint64_t)tile * RT, p0 = tile_start + (uint64_t)threadIdx.x * 16;
   uint8_t prev = 0;
   if (p0 > 0 && p0 - 1 < N) prev = in[p0 - 1];
   uint32_t first = 0xFFFFFFFFu, last = 0;
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256) void rle_tile_summary(const uint8_t* __restric
   if (threadIdx.x == 0) {
     uint32_t f = smin[0], l = smax[0];
     for (int i = 1; i < 4; i++) { f = smin[i] < f ? smin[i] : f; l = smax[i] > l ? smax[i] : l; }
-    fb[blockIdx.x] = f == 0xFFFFFFFFu ? 0 : tile_start + f + 1;
-    lb[blockIdx.x] = l ? tile_start + l : 0;     // (tile_start + l-1) + 1
+    fb[tile] = f == 0xFFFFFFFFu ? 0 : tile_start + f + 1;
+    lb[tile] = l ? tile_start + l : 0;     // (tile_start + l-1) + 1
   }
 }
 
@@ -109,13 +110,14 @@ __global__ __launch_bounds__(256) void rle_tile_summary(const uint8_t* __restric
 //          (used by the speculative boundary search): subpre = emitted bytes of the tile before the subtile,
 //          dmod = chunk phase (offset in run mod 255) of the subtile's first byte
 __global__ __launch_bounds__(256) void rle_tile_count(const uint8_t* __restrict__ in, uint64_t N, const uint64_t* __restrict__ run_start_in,
-                                                      uint64_t* __restrict__ gt, uint16_t* __restrict__ subpre, uint8_t* __restrict__ dmod) {
+                                                      uint64_t* __restrict__ gt, uint16_t* __restrict__ subpre, uint8_t* __restrict__ dmod, uint32_t t0) {
   __shared__ uint32_t smem[256 + 16];
-  const uint64_t tile_start = (uint64_t)blockIdx.x * RT;
+  const uint32_t tile = t0 + blockIdx.x;
+  const uint64_t tile_start = (uint64_t)tile * RT;
   uint8_t b[16]; uint32_t bm; uint64_t rs;
-  run_starts<256, 16>(in, N, tile_start, run_start_in[blockIdx.x], smem, b, bm, rs);
+  run_starts<256, 16>(in, N, tile_start, run_start_in[tile], smem, b, bm, rs);
   const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * 16;
-  if ((threadIdx.x & 15) == 0) dmod[(size_t)blockIdx.x * 16 + (threadIdx.x >> 4)] = (uint8_t)(p0 < N ? (((bm & 1u) ? 0ull : p0 - rs) % 255) : 0);
+  if ((threadIdx.x & 15) == 0) dmod[(size_t)tile * 16 + (threadIdx.x >> 4)] = (uint8_t)(p0 < N ? (((bm & 1u) ? 0ull : p0 - rs) % 255) : 0);
   uint32_t cnt = 0;
   // offset in the run mod 255: one 64-bit remainder per thread, then +1 per byte (0 at a run start)
   uint32_t dp = p0 < N ? (uint32_t)((p0 - rs) % 255) : 0u;
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(256) void rle_tile_count(const uint8_t* __restrict_
   }
   uint32_t tot;
   const uint32_t ex = block_excl_sum<256>(cnt, smem, tot);
-  if ((threadIdx.x & 15) == 0) subpre[(size_t)blockIdx.x * 16 + (threadIdx.x >> 4)] = (uint16_t)ex;
-  if (threadIdx.x == 0) gt[blockIdx.x] = tot;
+  if ((threadIdx.x & 15) == 0) subpre[(size_t)tile * 16 + (threadIdx.x >> 4)] = (uint16_t)ex;
+  if (threadIdx.x == 0) gt[tile] = tot;
 }
 
 // ---- P4: exclusive prefix sum (u64) over tiles, one workgroup; gt[Tn] = total
@@ -179,8 +181,10 @@ __global__ __launch_bounds__(1024) void rle_scanb_mid(unsigned long long* __rest
     scarry = cmx > scarry ? cmx : scarry;
   }
 }
-__global__ __launch_bounds__(1024) void rle_scanb_apply(uint64_t* __restrict__ fb, uint64_t* __restrict__ lb, uint32_t Tn, uint64_t N,
-                                                        const unsigned long long* __restrict__ agg, uint32_t nch) {
+// carry[0] = (last boundary in front of the scanned tile range) + 1, 0 = none; carry[1] = first boundary behind the range, N = none
+// (a rank of a multi-GPU job scans only its share of the tiles: rle_probe finds the two)
+__global__ __launch_bounds__(1024) void rle_scanb_apply(uint64_t* __restrict__ fb, uint64_t* __restrict__ lb, uint32_t Tn,
+                                                        const unsigned long long* __restrict__ agg, uint32_t nch, const uint64_t* __restrict__ carry_io) {
   __shared__ unsigned long long sm[16];
   __shared__ unsigned long long arr[1024];
   {                                                              // run start of each tile's first byte: exclusive prefix max of lb
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(1024) void rle_scanb_apply(uint64_t* __restrict__ f
     __syncthreads();
     const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
     __syncthreads();
-    if (i < Tn) { const unsigned long long e = prev > carry ? prev : carry; lb[i] = e ? e - 1 : 0ull; }
+    if (i < Tn) { unsigned long long e = prev > carry ? prev : carry; const unsigned long long c0 = carry_io[0]; e = e > c0 ? e : c0; lb[i] = e ? e - 1 : 0ull; }
   }
   {                                                              // next boundary after each tile: exclusive suffix min of fb
     const uint32_t i = blockIdx.x * SC + (1023 - threadIdx.x);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(1024) void rle_scanb_apply(uint64_t* __restrict__ f
     __syncthreads();
     const unsigned long long prev = threadIdx.x ? arr[threadIdx.x - 1] : 0ull;
     __syncthreads();
-    if (i < Tn) { const unsigned long long e = prev > scarry ? prev : scarry; fb[i] = e ? (NONE64 - e) - 1 : N; }
+    if (i < Tn) { const unsigned long long e = prev > scarry ? prev : scarry; fb[i] = e ? (NONE64 - e) - 1 : carry_io[1]; }
   }
 }
 __global__ __launch_bounds__(1024) void rle_scanc_reduce(const uint64_t* __restrict__ gt, uint32_t Tn, unsigned long long* __restrict__ agg, uint32_t nch) {
@@ -469,6 +473,80 @@ __global__ __launch_bounds__(1024) void rle_walk(const uint8_t* __restrict__ in,
     }
   }
   if (threadIdx.x == 0) { *nblocks_out = k; g_walk_dbg[0] = dbg_n[0]; g_walk_dbg[1] = dbg_n[1]; g_walk_dbg[2] = dbg_t[0]; g_walk_dbg[3] = dbg_t[1]; g_walk_dbg[4] = dbg_p[0]; g_walk_dbg[5] = dbg_p[1]; g_walk_dbg[6] = dbg_p[2]; }
+}
+
+
+// ---- multi-GPU jobs: a rank makes the tile tables of ITS share of the tiles only (tiles [t0, t1)).  What the tile scans
+// would have carried in from the other tiles is found by looking at the input itself (every rank holds the stream): the last
+// run boundary in front of tile t0 and the first one at or behind tile t1 -- nearly always inside the neighbouring tile; a
+// giant run makes the probe walk on, 16 KiB per step.  carry[0] = (last boundary position) + 1 or 0, carry[1] = first
+// boundary position or N (see rle_scanb_apply).  One workgroup.
+__global__ __launch_bounds__(1024) void rle_probe(const uint8_t* __restrict__ in, uint64_t N, uint32_t t0, uint32_t t1, uint64_t* __restrict__ carry) {
+  __shared__ unsigned long long sm[16];
+  const uint64_t lo = (uint64_t)t0 * RT, hi = (uint64_t)t1 * RT < N ? (uint64_t)t1 * RT : N;
+  unsigned long long back = 0;
+  for (uint64_t wend = lo; wend > 0 && !back;) {                      // windows [wend - 16 KiB, wend), walking towards 0
+    const uint64_t wbeg = wend > 16384 ? wend - 16384 : 0;
+    const uint64_t p0 = wbeg + (uint64_t)threadIdx.x * 16;
+    unsigned long long mine = 0;
+    if (p0 < wend) {
+      uint8_t b[16];
+      load16(in, N, p0, b);
+      uint8_t prev = p0 ? in[p0 - 1] : 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint64_t p = p0 + j;
+        if (p < wend && (p == 0 || b[j] != prev)) mine = p + 1;
+        prev = b[j];
+      }
+    }
+    back = block_incl_max<1024>(mine, sm);
+    __syncthreads();
+    if (threadIdx.x == 1023) sm[0] = back;
+    __syncthreads();
+    back = sm[0];
+    __syncthreads();
+    wend = wbeg;
+  }
+  unsigned long long fwd = N;
+  for (uint64_t wbeg = hi; wbeg < N && fwd == N; wbeg += 16384) {
+    const uint64_t p0 = wbeg + (uint64_t)threadIdx.x * 16;
+    unsigned long long mine = 0;                                      // NONE64 - position of the first boundary, 0 = none
+    if (p0 < N) {
+      uint8_t b[16];
+      load16(in, N, p0, b);
+      uint8_t prev = p0 ? in[p0 - 1] : 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint64_t p = p0 + j;
+        if (p < N && !mine && (p == 0 || b[j] != prev)) mine = NONE64 - p;
+        prev = b[j];
+      }
+    }
+    const unsigned long long m = block_incl_max<1024>(mine, sm);
+    __syncthreads();
+    if (threadIdx.x == 1023) sm[0] = m;
+    __syncthreads();
+    if (sm[0]) fwd = NONE64 - sm[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { carry[0] = back; carry[1] = fwd; }
+}
+// the whole stream's tile tables from the ranks' shares, gathered back to back (share r = tiles [r*tpr, (r+1)*tpr) in the layout
+// of Rle1Work::tile_share): one thread per tile
+__global__ __launch_bounds__(256) void rle_tables_unpack(const uint8_t* __restrict__ recv, uint32_t tpr, uint32_t Tn, uint64_t* __restrict__ fb, uint64_t* __restrict__ lb,
+                                                         uint64_t* __restrict__ gt, uint16_t* __restrict__ subpre, uint8_t* __restrict__ dmod) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tn) return;
+  const uint32_t r = t / tpr, j = t - r * tpr;
+  const uint8_t* base = recv + (size_t)r * Rle1Work::share_bytes(tpr);
+  lb[t] = reinterpret_cast<const uint64_t*>(base)[j];
+  fb[t] = reinterpret_cast<const uint64_t*>(base + (size_t)8 * tpr)[j];
+  gt[t] = reinterpret_cast<const uint64_t*>(base + (size_t)16 * tpr)[j];
+  const uint4* sp = reinterpret_cast<const uint4*>(base + (size_t)24 * tpr) + (size_t)2 * j;
+  uint4* dp = reinterpret_cast<uint4*>(subpre + (size_t)t * 16);
+  dp[0] = sp[0]; dp[1] = sp[1];
+  reinterpret_cast<uint4*>(dmod + (size_t)t * 16)[0] = (reinterpret_cast<const uint4*>(base + (size_t)56 * tpr))[j];
 }
 
 // ---- R: materialise the RLE1 bytes of every block (grid = input tiles)
@@ -781,18 +859,47 @@ int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, c
   return 0;
 }
 
-// Stage 0a: block boundaries of the whole stream d_in[0..N).  Leaves descriptors / lengths on the device,
-// returns the number of blocks in *nblocks_host (syncs the stream).
-int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host, uint32_t* last_len_host) {
+// Stage 0a, first half: the tile tables (run start carried into each tile, next boundary behind it, emitted bytes under the
+// global chunking, subtile tables) of tiles [t0, t1) of d_in[0..N).  `share` null: into the workspace's own arrays (absolute
+// tile index); else into a share buffer of Rle1Work::share_bytes(tpr) bytes that a multi-GPU job exchanges (tile t0 first).
+int rle1_tiles(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t t0, uint32_t t1, uint8_t* share, uint32_t tpr) {
   if (N > w.max_in) return CJS_E_INVALID_ARG;
-  if (N == 0) { *nblocks_host = 0; CJS_HIP_TRY(hipMemsetAsync(w.nblocks, 0, 4, s)); return 0; }
   const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
-  hipLaunchKernelGGL(rle_tile_summary, dim3(Tn), dim3(256), 0, s, d_in, N, w.fb, w.lb);
-  const uint32_t nch = (Tn + SC - 1) / SC;
-  hipLaunchKernelGGL(rle_scanb_reduce, dim3(nch), dim3(1024), 0, s, w.fb, w.lb, Tn, w.agg, nch);
+  if (t1 > Tn) t1 = Tn;
+  if (t0 >= t1) return 0;
+  uint64_t *fb = w.fb, *lb = w.lb, *gt = w.gt; uint16_t* subpre = w.subpre; uint8_t* dmod = w.dmod;
+  if (share) {                                       // kernels index by absolute tile: tile t0 is entry 0 of the share
+    if (t1 - t0 > tpr) return CJS_E_INVALID_ARG;
+    lb = reinterpret_cast<uint64_t*>(share) - t0; fb = reinterpret_cast<uint64_t*>(share + (size_t)8 * tpr) - t0;
+    gt = reinterpret_cast<uint64_t*>(share + (size_t)16 * tpr) - t0;
+    subpre = reinterpret_cast<uint16_t*>(share + (size_t)24 * tpr) - (size_t)t0 * 16; dmod = share + (size_t)56 * tpr - (size_t)t0 * 16;
+  }
+  const uint32_t Tl = t1 - t0, nch = (Tl + SC - 1) / SC;
+  uint64_t* carry = reinterpret_cast<uint64_t*>(w.nblocks + 4);      // two u64 behind the block count
+  hipLaunchKernelGGL(rle_tile_summary, dim3(Tl), dim3(256), 0, s, d_in, N, fb, lb, t0);
+  hipLaunchKernelGGL(rle_probe, dim3(1), dim3(1024), 0, s, d_in, N, t0, t1, carry);
+  hipLaunchKernelGGL(rle_scanb_reduce, dim3(nch), dim3(1024), 0, s, fb + t0, lb + t0, Tl, w.agg, nch);
   hipLaunchKernelGGL(rle_scanb_mid, dim3(1), dim3(1024), 0, s, w.agg, nch);
-  hipLaunchKernelGGL(rle_scanb_apply, dim3(nch), dim3(1024), 0, s, w.fb, w.lb, Tn, N, w.agg, nch);
-  hipLaunchKernelGGL(rle_tile_count, dim3(Tn), dim3(256), 0, s, d_in, N, w.lb, w.gt, w.subpre, w.dmod);
+  hipLaunchKernelGGL(rle_scanb_apply, dim3(nch), dim3(1024), 0, s, fb + t0, lb + t0, Tl, w.agg, nch, carry);
+  hipLaunchKernelGGL(rle_tile_count, dim3(Tl), dim3(256), 0, s, d_in, N, lb, gt, subpre, dmod, t0);
+  CJS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+// the gathered shares of all ranks (rank-major, share r = tiles [r*tpr, (r+1)*tpr)) -> the workspace's arrays
+int rle1_tables_from_shares(hipStream_t s, Rle1Work& w, uint64_t N, const uint8_t* d_recv, uint32_t tpr) {
+  const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
+  if (!Tn) return 0;
+  hipLaunchKernelGGL(rle_tables_unpack, dim3((Tn + 255) / 256), dim3(256), 0, s, d_recv, tpr, Tn, w.fb, w.lb, w.gt, w.subpre, w.dmod);
+  CJS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+// Stage 0a, second half: prefix of the emitted bytes over the tiles and the boundary walk.  Leaves descriptors / lengths on the
+// device, returns the number of blocks in *nblocks_host (syncs the stream).
+int rle1_walk_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host, uint32_t* last_len_host) {
+  if (N > w.max_in) return CJS_E_INVALID_ARG;
+  if (N == 0) { *nblocks_host = 0; if (last_len_host) *last_len_host = 0; CJS_HIP_TRY(hipMemsetAsync(w.nblocks, 0, 4, s)); return 0; }
+  const uint32_t Tn = (uint32_t)((N + RT - 1) / RT);
+  const uint32_t nch = (Tn + SC - 1) / SC;
   hipLaunchKernelGGL(rle_scanc_reduce, dim3(nch), dim3(1024), 0, s, w.gt, Tn, w.agg, nch);
   hipLaunchKernelGGL(rle_scanc_mid, dim3(1), dim3(1024), 0, s, w.agg, nch, w.gt, Tn);
   hipLaunchKernelGGL(rle_scanc_apply, dim3(nch), dim3(1024), 0, s, w.gt, Tn, w.agg, nch);
@@ -811,6 +918,12 @@ int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32
               (unsigned long long)d[1], d[3] / 100.0, w.h_n[0], d[4] / 100.0, d[5] / 100.0, d[6] / 100.0);
   }
   return 0;
+}
+// Stage 0a: block boundaries of the whole stream d_in[0..N) on one GPU
+int rle1_run(hipStream_t s, Rle1Work& w, const uint8_t* d_in, uint64_t N, uint32_t* nblocks_host, uint32_t* last_len_host) {
+  if (N > w.max_in) return CJS_E_INVALID_ARG;
+  if (N) CJS_TRY(rle1_tiles(s, w, d_in, N, 0u, (uint32_t)((N + RT - 1) / RT), nullptr, 0u));
+  return rle1_walk_run(s, w, d_in, N, nblocks_host, last_len_host);
 }
 
 // Stage 0b: RLE1 bytes (d_blocks, block k at (k-first)*cap) and CRCs (block_crc[k], absolute) of blocks [first, first+count)

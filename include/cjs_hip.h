@@ -121,6 +121,37 @@ int cjs_bzip2_compress_device_range(cjs_ctx *ctx, const uint8_t *d_in, size_t n,
                                     uint64_t *out_bits, uint32_t *block_crcs, long crc_cap,
                                     long *total_blocks, cjs_stats *stats);
 
+/* ---- one process (or thread) per GPU: the three phases of a multi-GPU Bzip2.compressFile (replaces the block
+ * loop J/Bzip2_joined_.js:2233-2247 for `world` GPUs).  Every rank holds the stream in its GPU's memory.  The library calls no
+ * collective: between the phases the CALLER exchanges two small tables with whatever transport it owns (bench.py:
+ * torch.distributed all_gather over RCCL; cjs_bzip2_compress with n_devices > 1: worker threads and host memory).
+ *   1. cjs_bzip2_shard_tiles : boundary tables of this rank's share of the 4 KiB input tiles -> d_share
+ *                              (cjs_bzip2_shard_share_bytes(n, world) bytes, the same for every rank);
+ *      exchange: all-gather of the shares, rank order, back to back -> d_shares (world x share bytes);
+ *   2. cjs_bzip2_shard_blocks: block boundaries of the stream (replicated: serial by the format, Q1-Q3), then this rank's
+ *                              contiguous range of blocks through RLE1 / CRC / BWT / MTF / Huffman tables -> *meta;
+ *                              world == 1 may pass d_shares = NULL (no phase 1);
+ *      exchange: all-gather of the metas (32 bytes per rank);
+ *   3. cjs_bzip2_shard_pack  : the rank's blocks at their FINAL bit offset.  The ranks' fragments are disjoint runs of whole
+ *                              32-bit words of the one .bz2 stream: bytes [frag_off, frag_off + frag_len) of d_out are stream
+ *                              bytes [stream_off, stream_off + frag_len); rank 0 writes 'BZh<level>', the last rank with blocks
+ *                              the trailer and the combined CRC.  The word two ranks share is completed by the earlier one
+ *                              (what follows is always the 48-bit block magic).  *stream_len (optional) = length of the stream.
+ * Each call is synchronous (the context's stream has drained on return). */
+typedef struct cjs_shard_meta {
+  uint64_t bits;          /* bit length of this rank's blocks, without header / trailer */
+  uint64_t total_blocks;  /* blocks of the whole stream (must agree between the ranks) */
+  uint64_t first_block;   /* this rank's contiguous range: [first_block, first_block + blocks) */
+  uint32_t blocks;
+  uint32_t crc_fold;      /* the range's block CRCs folded from 0: c = rol1(c) ^ crc (J/Bzip2_joined_.js:2237) */
+} cjs_shard_meta;
+size_t cjs_bzip2_shard_share_bytes(size_t n, int world);
+int cjs_bzip2_shard_tiles(cjs_ctx *ctx, const uint8_t *d_in, size_t n, int rank, int world, void *d_share);
+int cjs_bzip2_shard_blocks(cjs_ctx *ctx, const uint8_t *d_in, size_t n, int level, int rank, int world, const void *d_shares,
+                           cjs_shard_meta *meta, cjs_stats *stats);
+int cjs_bzip2_shard_pack(cjs_ctx *ctx, int level, int rank, int world, const cjs_shard_meta *metas, uint8_t *d_out, size_t out_cap,
+                         size_t *frag_off, size_t *frag_len, uint64_t *stream_off, uint64_t *stream_len);
+
 /* ---- stage-level entry points (host buffers; used by the parity tests to localise a mismatch).
  * in = nb consecutive blocks of block_len bytes (last one may be shorter).
  * cjs_stage_bwt: cyclic!=0 -> BWT.bwtransform2 semantics (J/Bzip2_joined_.js:928-971, Q4),
