@@ -292,8 +292,8 @@ def main():
         share_bytes = ctx.share_bytes(stream_bytes, n_gpus)
         d_share = torch.zeros(share_bytes, dtype=torch.uint8, device=dev)
         d_shares = torch.zeros(share_bytes * n_gpus, dtype=torch.uint8, device=dev)
-        meta_dev = torch.zeros(4, dtype=torch.int64, device=dev if use_nccl else "cpu")
-        metas_dev = torch.zeros(4 * n_gpus, dtype=torch.int64, device=dev if use_nccl else "cpu")
+        meta_dev = torch.zeros(5, dtype=torch.int64, device=dev if use_nccl else "cpu")
+        metas_dev = torch.zeros(5 * n_gpus, dtype=torch.int64, device=dev if use_nccl else "cpu")
 
     def gather_shares():
         if use_nccl:
@@ -306,19 +306,19 @@ def main():
             torch.cuda.current_stream().synchronize()
 
     def gather_metas(m):
-        mine = torch.tensor([m.bits, m.total_blocks, m.first_block, m.blocks | (m.crc_fold << 32)], dtype=torch.int64)
+        mine = torch.tensor([m.bits, m.total_blocks, m.first_block, m.blocks, m.crc_fold], dtype=torch.int64)
         if use_nccl:
             meta_dev.copy_(mine)
             dist.all_gather_into_tensor(metas_dev, meta_dev)
             allm = metas_dev.cpu().tolist()
         else:
-            parts = [torch.empty(4, dtype=torch.int64) for _ in range(n_gpus)]
+            parts = [torch.empty(5, dtype=torch.int64) for _ in range(n_gpus)]
             dist.all_gather(parts, mine)
             allm = torch.cat(parts).tolist()
         out = []
         for r in range(n_gpus):
-            b, t, f, bc = allm[4 * r: 4 * r + 4]
-            out.append(pkg.ShardMeta(b, t, f, bc & 0xFFFFFFFF, (bc >> 32) & 0xFFFFFFFF))
+            b, t, f, nblk, fold = allm[5 * r: 5 * r + 5]
+            out.append(pkg.ShardMeta(b, t, f, nblk, fold))
         return out
 
     def step(stats=None):
@@ -343,13 +343,13 @@ def main():
     agg = {"dom_ms": 0.0, "dom_launches": 0, "dom_elems": 0, "stage": {}, "step_ms": []}
     barrier()
     torch.cuda.synchronize()
+    ctx.set_stage_times(False)
     t0 = time.perf_counter()
     res = None
     for _ in range(args.steps):
-        # inside the timed loop the library only records events (whole call + every launch of the dominant kernel): the
+        # inside the timed loop the library only records events (whole call + every full-size launch of the dominant kernel): the
         # per-stage times need a stream synchronisation per stage and come from one extra, untimed step below
         st = pkg.Stats()
-        st.flags = pkg.Stats.NO_STAGE_TIMES
         res = step(st)
         agg["dom_ms"] += st.ms_bwt_dominant * st.bwt_dominant_launches
         agg["dom_launches"] += st.bwt_dominant_launches
@@ -360,6 +360,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st = pkg.Stats()
+    ctx.set_stage_times(True)
     step(st)                                             # untimed: stage breakdown (synchronises between the stages)
     for k in ("ms_total", "ms_rle1", "ms_bwt", "ms_mtf", "ms_huff", "ms_pack"):
         agg["stage"][k] = getattr(st, k) * args.steps

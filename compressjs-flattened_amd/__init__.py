@@ -28,8 +28,7 @@ class Stats(ctypes.Structure):
                 ("ms_mtf", ctypes.c_double), ("ms_huff", ctypes.c_double), ("ms_pack", ctypes.c_double),
                 ("ms_bwt_dominant", ctypes.c_double), ("bwt_dominant_launches", ctypes.c_uint64),
                 ("bwt_dominant_bytes", ctypes.c_uint64), ("blocks", ctypes.c_uint64), ("bytes_in", ctypes.c_uint64),
-                ("bytes_out", ctypes.c_uint64), ("bwt_rounds", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
-    NO_STAGE_TIMES = 1          # CJS_STATS_NO_STAGE_TIMES: no stream synchronisation between the stages
+                ("bytes_out", ctypes.c_uint64), ("bwt_rounds", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -77,6 +76,8 @@ def load_library():
     L.cjs_ctx_create_sharded.argtypes = [ctypes.POINTER(V), I, S, ctypes.c_long, I]
     L.cjs_ctx_destroy.argtypes = [V]
     L.cjs_ctx_destroy.restype = None
+    L.cjs_ctx_set_stage_times.argtypes = [V, I]
+    L.cjs_ctx_set_stage_times.restype = None
     L.cjs_bzip2_compress_device.argtypes = [V, V, S, I, V, S, PS, ctypes.POINTER(Stats)]
     L.cjs_bzip2_compress_device_range.argtypes = [V, V, S, I, ctypes.c_long, ctypes.c_long, V, S, ctypes.POINTER(ctypes.c_uint64),
                                                   V, ctypes.c_long, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(Stats)]
@@ -188,6 +189,10 @@ class DeviceContext:
         self.h = ctypes.c_void_p()
         self.level = level
         _check(self.L.cjs_ctx_create_sharded(ctypes.byref(self.h), device, max_input, max_range_blocks, level))
+
+    def set_stage_times(self, on):
+        """stats of later calls: per-stage times (a stream synchronisation per stage) or events only"""
+        self.L.cjs_ctx_set_stage_times(self.h, 1 if on else 0)
 
     def close(self):
         if self.h:

@@ -63,6 +63,15 @@ struct PoolBuf { void* p; size_t bytes; int device; bool busy; };
 std::mutex g_pool_mu;
 std::vector<PoolBuf> g_pool;
 }  // namespace
+// Fit rule (the same as HostPool's): requests below 1 MiB are plain allocations of their own size class and never claim a big
+// idle buffer; a cached buffer serves a request only if it is at most twice as large.  give() keeps at most
+// CJS_DEVICE_POOL_MB (default 65536) of idle buffers per process: beyond that the largest idle ones are freed.
+namespace {
+size_t dev_idle_limit() {
+  static const size_t mb = getenv("CJS_DEVICE_POOL_MB") ? (size_t)strtoull(getenv("CJS_DEVICE_POOL_MB"), nullptr, 10) : 65536;
+  return mb << 20;
+}
+}  // namespace
 void* DevPool::take(size_t bytes) {
   if (!bytes) bytes = 4;
   int dev = 0;
@@ -70,7 +79,8 @@ void* DevPool::take(size_t bytes) {
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     PoolBuf* best = nullptr;
-    for (auto& b : g_pool) if (!b.busy && b.device == dev && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    for (auto& b : g_pool)
+      if (!b.busy && b.device == dev && b.bytes >= bytes && (b.bytes / 2 <= bytes || b.bytes <= ((size_t)1 << 20)) && (!best || b.bytes < best->bytes)) best = &b;
     if (best) { best->busy = true; return best->p; }
   }
   void* p = nullptr;
@@ -87,8 +97,18 @@ void DevPool::give(void* p) {
   static const bool no_cache = getenv("CJS_NO_CTX_CACHE") != nullptr;
   std::lock_guard<std::mutex> lock(g_pool_mu);
   for (size_t i = 0; i < g_pool.size(); i++) if (g_pool[i].p == p) {
-    if (no_cache) { (void)hipFree(p); g_pool.erase(g_pool.begin() + (long)i); }
-    else g_pool[i].busy = false;
+    if (no_cache) { (void)hipFree(p); g_pool.erase(g_pool.begin() + (long)i); return; }
+    g_pool[i].busy = false;
+    size_t idle = 0;
+    for (auto& b : g_pool) if (!b.busy) idle += b.bytes;
+    while (idle > dev_idle_limit()) {                    // over the limit: the largest idle buffers go first
+      size_t big = g_pool.size();
+      for (size_t k = 0; k < g_pool.size(); k++) if (!g_pool[k].busy && (big == g_pool.size() || g_pool[k].bytes > g_pool[big].bytes)) big = k;
+      if (big == g_pool.size()) break;
+      idle -= g_pool[big].bytes;
+      (void)hipFree(g_pool[big].p);                      // (hipFree finds the owning device from the pointer)
+      g_pool.erase(g_pool.begin() + (long)big);
+    }
     return;
   }
   (void)hipFree(p);                                      // not ours: plain buffer
@@ -127,7 +147,7 @@ void* HostPool::take(size_t bytes) {
   }
   void* p = nullptr;
   const size_t cap = bytes + bytes / 16;                 // a later result of about the same size fits too
-  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) { (void)hipGetLastError(); return malloc(bytes); }
+  if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess || !p)      // (portable: every GPU of a multi-device call copies into it) { (void)hipGetLastError(); return malloc(bytes); }
   std::lock_guard<std::mutex> lock(g_host_mu);
   g_host.push_back(HostBuf{p, cap, true});
   return p;

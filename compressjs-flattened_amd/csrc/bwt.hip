@@ -54,8 +54,9 @@ __device__ __forceinline__ TileRef tile_ref(const SegGeom& sg, uint32_t tile) {
 // written for them).  key = leading nsym symbols | block parity above them (adjacent blocks must not compare equal);
 // cyclic: bytes, wrapping; sentinel: 9-bit symbols byte+1, 0 = past the end.  value = position in the block.
 struct GenSrc { const uint8_t* T; int cyclic, nsym, packed; };
-// packed records (cyclic round 1, CJS_R1_PACKED): ONE u64 per suffix = 5 leading bytes (bits 63..24) | block parity (bit 20) |
-// position in the block (bits 19..0): a radix pass moves 8 B per suffix each way instead of 12, and there is no value array
+// packed records (cyclic round 1): ONE u64 per suffix = 5 bytes (bits 63..24) | block parity (bit 20) | position in the block
+// (bits 19..0): a radix pass moves 8 B per suffix each way instead of 12, and there is no value array.  The first phase sorts by
+// bytes 2..6 of the suffix (packed == 2, the only packed form)
 constexpr int PK_SHIFT = 20, PK_KEY_LO = 24;
 constexpr uint32_t PK_POS_MASK = (1u << PK_SHIFT) - 1u;
 // records of the two-phase sort after bwt_phase2_records: byte0 . byte1 (63..48) | rank of the class of bytes 2..6 (47..28) | the byte IN
@@ -91,8 +92,7 @@ __device__ __forceinline__ uint64_t gen_key(const GenSrc& gs, const SegGeom& sg,
   uint64_t k = 0;
   if (gs.cyclic) {
     k = ((uint64_t)__builtin_bswap32(lo) << 24) | (uint64_t)(__builtin_bswap32(hi) >> 8);     // 7 bytes, first byte on top
-    if (gs.packed == 1) return ((k >> 16) << PK_KEY_LO) | ((uint64_t)(t.seg & 1u) << PK_SHIFT) | (uint64_t)(t.off + loc);          // bytes 0..4
-    if (gs.packed == 2) return ((k & 0xFFFFFFFFFFull) << PK_KEY_LO) | ((uint64_t)(t.seg & 1u) << PK_SHIFT) | (uint64_t)(t.off + loc);  // bytes 2..6 (two-phase sort)
+    if (gs.packed) return ((k & 0xFFFFFFFFFFull) << PK_KEY_LO) | ((uint64_t)(t.seg & 1u) << PK_SHIFT) | (uint64_t)(t.off + loc);  // bytes 2..6 (two-phase sort)
     k >>= 8 * (7 - gs.nsym);
     k |= (uint64_t)(t.seg & 1u) << (8 * gs.nsym);
   } else {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, SegGe
 // With delta > 0 the bytes are the block TEXT (cyclic form): the first pass's digit of the suffix at position p is the text byte
 // at p + delta, so a tile's digits are the text bytes [off + delta, off + delta + nvalid) of its block -- no keys are built for
 // the count (rs_hist<GEN>: 130 us); the one tile per block whose range wraps around the block end counts byte by byte.
-template <int HB>       // histogram copies per wave (the zeroing and folding of 4 * 256 * HB counters is most of this kernel's LDS traffic)
+constexpr int HB = 4;   // histogram copies per wave (the zeroing and folding of 4 * 256 * HB counters is most of this kernel's LDS traffic; 59-82 us per 100 M keys with 4, 72-85 with 8, 75-130 with 2)
 __global__ __launch_bounds__(256) void rs_hist_bytes(const uint8_t* __restrict__ dig, SegGeom sg, uint32_t* __restrict__ hist, uint32_t delta) {
   __shared__ uint32_t h[4 * 256 * HB];
   const int tid = threadIdx.x;
@@ -363,28 +363,14 @@ __global__ __launch_bounds__(256) void bwt_init_keys(const uint8_t* __restrict__
 }
 
 // Two-sweep scheduling of the round-1 rank scatter: a block's 3.6 MB rank region does not survive in a 4 MiB L2 next to
-// the streamed arrays (PMC: ~64 B of memory traffic per 4-byte store), so blocks are dealt to the XCDs round-robin
-// (workgroup 8j+x -> XCD x) and each XCD walks the tiles of one block twice, storing first the ranks of the lower half
-// of the block's text positions, then the upper half (1.8 MB per sweep).  `slots` tile slots per (block, sweep).
+// the streamed arrays (PMC: ~64 B of memory traffic per 4-byte store), so the tiles are walked twice, storing first the ranks
+// of the lower half of every block's text positions, then the upper half (1.8 MB per sweep and block; the tiles of a block
+// stay on one XCD, see xcd_tile).
 // PMC: WRITE_SIZE of the kernel 6.66 -> 2.67 GB per 100 MB step; its time 1.64 -> 1.35 ms (the second sweep re-reads and
 // re-derives the group structure).  The same scheduling applied to the gather / scatter of rounds >= 2 over the compacted
 // arrays (per-block start table from a binary search) was measured SLOWER (gather 0.84 -> 1.07 ms, scatter 1.24 -> 1.84 ms
 // in round 2) and is not kept.
-struct HalfMap { uint32_t halves, slots, stride; };
-__device__ __forceinline__ bool half_map(const HalfMap& hm, uint32_t nb, uint32_t A, uint32_t T, uint32_t& tile, uint32_t& half) {
-  half = 0;
-  if (hm.halves <= 1) { tile = xcd_tile(blockIdx.x, T); return tile < T; }
-  const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = 2u * hm.slots;
-  const uint32_t bi = j / per, r = j - bi * per, blk = x + 8u * bi;
-  half = r / hm.slots;
-  if (blk >= nb) return false;
-  const uint64_t s0 = (uint64_t)blk * hm.stride, s1 = blk + 1 == nb ? (uint64_t)A : (uint64_t)(blk + 1) * hm.stride;
-  const uint32_t ft = (uint32_t)((s0 + RS_TILE - 1) / RS_TILE);       // a tile belongs to the block of its first element
-  uint32_t fe = (uint32_t)((s1 + RS_TILE - 1) / RS_TILE);
-  if (fe > T) fe = T;
-  tile = ft + (r - half * hm.slots);
-  return tile < fe;
-}
+struct HalfMap { uint32_t halves, stride; };      // halves 2: the two sweeps are the launches SWEEP 1 and SWEEP 2 of bwt_apply
 
 // round r>=1 keys: (group ordinal, rank of suffix i+h)
 __global__ __launch_bounds__(256) void bwt_gather_keys(Geom g, int cyclic, uint32_t A, uint32_t h, const uint32_t* __restrict__ R,
@@ -535,8 +521,8 @@ __device__ __forceinline__ uint64_t class_head_before(const uint64_t* __restrict
 // regroup: new ranks -> R (scattered 4-byte stores), singletons -> SA, survivors compacted into the next
 // active arrays.  Fully lane-striped: the per-element prefix quantities come from 4096-bit masks
 // (wave ballots) + a 64-word scan, so every global access of a wave touches consecutive addresses.
-// `hm_`: two-sweep scheduling of the scattered rank stores (see HalfMap); everything but the ranks is written by sweep 0.
-// SWEEP 1 / 2 (round 1, packed records): the two sweeps as two launches with the tile scan between them, and NO counting pass
+// SWEEP 0: one launch behind a counting pass (bwt_flags + bwt_scan_tiles).
+// SWEEP 1 / 2 (round 1, packed records; see HalfMap): two launches with the tile scan between them, and NO counting pass
 // in front -- sweep 1 stores the ranks of the lower half-blocks and leaves the tile counts that bwt_flags would have made
 // (it finds the one class head it cannot see by search: class_head_before); sweep 2 stores the upper half and, with the
 // scanned counts, everything else.
@@ -552,9 +538,8 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   __shared__ uint64_t m_nh[64], m_sg[64], m_oh[64];
   __shared__ uint32_t wp_s[64], wp_h[64], wp_head[64];
   __shared__ uint32_t carry_s;
-  uint32_t tile, half;
-  if (SWEEP == 0) { if (!half_map(hm_, g.nb, A, T, tile, half)) return; }
-  else { tile = xcd_tile(blockIdx.x, T); half = SWEEP - 1; if (tile >= T) return; }
+  const uint32_t tile = xcd_tile(blockIdx.x, T), half = SWEEP == 2 ? 1u : 0u;
+  if (tile >= T) return;
   const uint32_t hsplit = hm_.stride >> 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const uint64_t base = (uint64_t)tile * RS_TILE;
@@ -640,7 +625,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
   uint32_t ub[16];
 #pragma unroll
   for (int it = 0; it < 16; it++) ub[it] = 0u;
-  const bool emits = U != nullptr && !(SWEEP == 0 ? half != 0 : SWEEP == 1);
+  const bool emits = U != nullptr && SWEEP != 1;
   if (emits && !carried) {
 #pragma unroll
     for (int it = 0; it < 16; it++) {
@@ -676,8 +661,8 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
       const uint32_t pb = PACKED ? (vraw >> PK2_PREV_SHIFT) & 0xFFu : vraw >> VAL_PREV_SHIFT;      // its carried byte, if any
       const uint32_t blk = p / g.stride;
       const uint32_t head_pos = p - ((uint32_t)a - head_a);
-      if (!keeps_rank && (hm_.halves <= 1 || (uint32_t)(vv >= hsplit) == half)) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
-      if (SWEEP == 0 ? half != 0 : SWEEP == 1) continue;
+      if (!keeps_rank && (SWEEP == 0 || (uint32_t)(vv >= hsplit) == half)) R[(size_t)blk * g.stride + vv] = head_pos - blk * g.stride;
+      if (SWEEP == 1) continue;
       if ((ms >> lane) & 1ull) {
         // a resolved suffix: its BWT byte goes straight to the output row (cyclic form: U[p] = T[suffix - 1], p in sorted-position
         // order) -- no suffix array is written, and the byte gathers overlap the rest of the regrouping instead of making a pass
@@ -705,7 +690,7 @@ __global__ __launch_bounds__(256) void bwt_apply(const uint64_t* __restrict__ ke
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t TS_WIN = 4096, TS_MAXGRP = 1024, TS_NOM = TS_WIN - TS_MAXGRP, TS_TINY = 64, TS_GT = 2048;
 
-// Fused rank gather (CJS_FUSE_GATHER, default): the tile sorters of rounds >= 2 make the round's keys themselves -- group
+// Fused rank gather: the tile sorters of rounds >= 2 make the round's keys themselves -- group
 // ordinal from gord[], rank of suffix val + h out of R -- instead of reading back a key array that bwt_gather_keys wrote: the
 // random rank fetches (bound by the number of 64-byte transactions) then overlap the VALU-bound sorting of the other
 // workgroups of the CU, and 16 B per suffix of key traffic are gone.  Windows overlap, so every slot has ONE window that
@@ -772,7 +757,6 @@ __device__ __forceinline__ void ts_ce(uint64_t& a, uint64_t& b, bool up) {
   const uint64_t x = sw ? b : a, y = sw ? a : b;
   a = x; b = y;
 }
-template <bool FUSED>
 __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
                                                      uint8_t* __restrict__ dflag, TsGather tg, uint32_t Tt) {
   __shared__ uint64_t sk[TS_WIN];
@@ -787,31 +771,13 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
   const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
   const uint32_t L = (uint32_t)(we - wb);
   uint64_t r[16];
-  uint32_t pv[16], go[16], pp[FUSED ? 16 : 1];          // go: group ordinal of slot it*256+tid
+  uint32_t pv[16], go[16], pp[16];          // go: group ordinal of slot it*256+tid
   uint32_t gprev;
-  // every global load of the window (keys and suffixes) is issued before the first LDS store: written as one loop the
-  // compiler waits for each load in turn, sixteen memory round trips instead of one
-  if constexpr (FUSED) {
+  // every global load of the window (ordinals, suffixes, positions) is issued before the first LDS store: written as one loop
+  // the compiler waits for each load in turn, sixteen memory round trips instead of one
+  {
     const uint32_t li = wave_max(ts_fused_load<false>(tg, val, wb, L, go, pv, pp, gprev));
     if (lane == 0) lired[w] = li;
-  } else {
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const uint32_t x = (uint32_t)it * 256u + tid;
-      r[it] = key[wb + (x < L ? x : L - 1u)];
-    }
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const uint32_t x = (uint32_t)it * 256u + tid;
-      pv[it] = val[wb + (x < L ? x : L - 1u)];
-    }
-    gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const uint32_t x = (uint32_t)it * 256u + tid;
-      if (x >= L) r[it] = ~0ull;
-      go[it] = (uint32_t)(r[it] >> 20);
-    }
   }
 #pragma unroll
   for (int it = 0; it < 16; it++) gk[(uint32_t)it * 256u + tid] = go[it];
@@ -844,7 +810,7 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
   int any_medium = 0;
   uint32_t hx16[16];          // head slot (low 16 bits) | group size (high 16 bits) of owned slots, 0xFFFFFFFF otherwise
   uint32_t prev_end = 0, needm = 0;
-  if constexpr (FUSED) {
+  {
     const uint32_t a01 = lired[0] > lired[1] ? lired[0] : lired[1], a23 = lired[2] > lired[3] ? lired[2] : lired[3];
     prev_end = ts_prev_end(wb, L, we == A, a01 > a23 ? a01 : a23, hm, wnext);
   }
@@ -867,15 +833,9 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
     const uint64_t mb = __ballot(medium);
     if (lane == 0) mm[wi] = mb;
     any_medium |= medium ? 1 : 0;
-    if constexpr (FUSED) needm |= (valid && x >= prev_end && (owned || x < TS_NOM)) ? 1u << it : 0u;
-    else {
-      const uint64_t k = r[it];
-      const uint64_t v = owned ? (uint64_t)pv[it] : 0ull;
-      r[it] = owned ? (((uint64_t)(uint32_t)hx << 52) | ((k & 0xFFFFFull) << 32) | v)
-                    : (((uint64_t)x << 52) | (0xFFFFFull << 32));
-    }
+    needm |= (valid && x >= prev_end && (owned || x < TS_NOM)) ? 1u << it : 0u;
   }
-  if constexpr (FUSED) {
+  {
     uint32_t rk20[16];
     ts_fused_gather(tg, needm, pv, pp, rk20);
 #pragma unroll
@@ -973,7 +933,6 @@ __global__ __launch_bounds__(256) void bwt_tile_sort(uint64_t* __restrict__ key,
 // composite (4 passes of 8 bits, wave64 match-any ranking, one LDS staging array) is then a permutation INSIDE every owned
 // group: exactly h slots carry a composite below (h << 20), so the members of the group headed at h land on [h, h + size).
 // The cost does not depend on the group sizes (the counting / bitonic version above degrades with them).
-template <bool FUSED>
 __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t A,
                                                            uint8_t* __restrict__ dflag, TsGather tg, uint32_t Tt) {
   __shared__ uint64_t se[TS_WIN];                // (composite << 32) | suffix: staging of a pass
@@ -990,33 +949,13 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
   const uint64_t we = (wb + TS_WIN < A) ? wb + TS_WIN : A;
   const uint32_t L = (uint32_t)(we - wb);
   // slot of (wave w, step s, lane): w * 1024 + s * 64 + lane -- array order = (w, s, lane) order, which the stable ranking needs
-  uint32_t rk20[16], go[16], pv[16], pp[FUSED ? 16 : 1];
+  uint32_t rk20[16], go[16], pv[16], pp[16];
   uint32_t gprev;
-  if constexpr (FUSED) {
+  {
     const uint32_t li = wave_max(ts_fused_load<true>(tg, val, wb, L, go, pv, pp, gprev));
     if (lane == 0) lired[w] = li;
 #pragma unroll
     for (int s = 0; s < 16; s++) gk[ts_slot<true>(s, tid)] = go[s];
-  } else {
-    uint64_t k[16];                              // every load is issued before the first LDS store
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
-      k[s] = key[wb + (x < L ? x : L - 1u)];
-    }
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
-      pv[s] = val[wb + (x < L ? x : L - 1u)];
-    }
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const uint32_t x = (uint32_t)w * 1024u + (uint32_t)s * 64u + lane;
-      if (x >= L) k[s] = ~0ull;
-      go[s] = (uint32_t)(k[s] >> 20); rk20[s] = (uint32_t)k[s] & 0xFFFFFu;
-      gk[x] = go[s];
-    }
-    gprev = wb ? (uint32_t)(key[wb - 1] >> 20) : 0xFFFFFFFFu;
   }
   __syncthreads();
 #pragma unroll
@@ -1042,7 +981,7 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
   }
   __syncthreads();
   uint32_t prev_end = 0;
-  if constexpr (FUSED) {
+  {
     const uint32_t a01 = lired[0] > lired[1] ? lired[0] : lired[1], a23 = lired[2] > lired[3] ? lired[2] : lired[3];
     prev_end = ts_prev_end(wb, L, we == A, a01 > a23 ? a01 : a23, hm, wnext);
   }
@@ -1061,10 +1000,9 @@ __global__ __launch_bounds__(256) void bwt_tile_sort_radix(uint64_t* __restrict_
     const bool owned = x < L && hx >= 0 && nx <= (int)L && (uint32_t)(nx - hx) <= TS_MAXGRP && (uint32_t)hx < TS_NOM;
     if (owned && dflag) dflag[wb + x] = 0;
     ownm |= owned ? 1u << s : 0u;
-    if constexpr (FUSED) { needm |= (x < L && x >= prev_end && (owned || x < TS_NOM)) ? 1u << s : 0u; comp[s] = (uint32_t)hx; }
-    else comp[s] = owned ? (((uint32_t)hx << 20) | rk20[s]) : (x << 20);
+    needm |= (x < L && x >= prev_end && (owned || x < TS_NOM)) ? 1u << s : 0u; comp[s] = (uint32_t)hx;
   }
-  if constexpr (FUSED) {
+  {
     ts_fused_gather(tg, needm, pv, pp, rk20);
 #pragma unroll
     for (int s = 0; s < 16; s++) {
@@ -1309,53 +1247,14 @@ __global__ __launch_bounds__(256) void bwt_pidx(Geom g, int cyclic, int leftover
   if (threadIdx.x == 0) pidx[blk] = r0 + cnt - 1u;
 }
 
+// BWT bytes of the sentinel form (BWTC) from the finished suffix array: rows shift by the primary index, which is only known at
+// the end, so this form keeps a suffix array and an emit pass (the cyclic form writes its bytes from the regroup kernels).
 // Tiles of 4096 positions, dealt to the XCDs in contiguous ranges: a block's text (the random-access side) is then
 // fetched into one L2 instead of all eight; the suffix array streams through non-temporally.
-__global__ __launch_bounds__(256) void bwt_emit(const uint8_t* __restrict__ T, Geom g, int cyclic, uint32_t M,
-                                                const uint32_t* __restrict__ SA, const uint32_t* __restrict__ R, uint8_t* __restrict__ U, uint32_t Tn) {
+__global__ __launch_bounds__(256) void bwt_emit_sentinel(const uint8_t* __restrict__ T, Geom g, uint32_t M,
+                                                         const uint32_t* __restrict__ SA, const uint32_t* __restrict__ R, uint8_t* __restrict__ U, uint32_t Tn) {
   const uint32_t tile = xcd_tile(blockIdx.x, Tn);
   if (tile >= Tn) return;
-  if (cyclic && (((uintptr_t)U | (uintptr_t)SA) & 15u) == 0) {
-    // U is one flat array in sorted-position order (u[p] of block blk is U[blk*stride + p]): four positions per lane,
-    // one 16-byte load of SA, four byte gathers from the block text, one aligned 32-bit store
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    if ((uint64_t)(tile + 1) * RS_TILE <= M) {       // whole tile: four SA loads, then sixteen byte gathers, then four stores
-      u32x4 s4[4];
-#pragma unroll
-      for (int it = 0; it < 4; it++)
-        s4[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(SA + (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u));
-      uint32_t outw[4];
-      const uint32_t t0 = tile * RS_TILE, blk0 = t0 / g.stride;          // (M is 32 bits wide: so is every position)
-      const uint64_t nextb = (uint64_t)(blk0 + 1) * g.stride;           // a tile touches two blocks at most when stride >= RS_TILE
-      const bool two = g.stride >= RS_TILE;
-#pragma unroll
-      for (int it = 0; it < 4; it++) {
-        const uint32_t a0 = t0 + ((uint32_t)it * 256 + threadIdx.x) * 4u;
-        const uint32_t sv[4] = {s4[it].x, s4[it].y, s4[it].z, s4[it].w};
-        uint32_t b[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t a = a0 + j;
-          const uint32_t blk = two ? blk0 + (a >= nextb ? 1u : 0u) : a / g.stride, n = blk_len(g, blk);
-          b[j] = T[(size_t)blk * g.stride + (sv[j] ? sv[j] - 1 : n - 1)];
-        }
-        outw[it] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-      }
-#pragma unroll
-      for (int it = 0; it < 4; it++)
-        *reinterpret_cast<uint32_t*>(U + (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u) = outw[it];
-      return;
-    }
-    for (int it = 0; it < 4; it++) {
-      const uint64_t a0 = (uint64_t)tile * RS_TILE + ((uint32_t)it * 256 + threadIdx.x) * 4u;
-      for (uint64_t a = a0; a < a0 + 4 && a < M; a++) {
-        const uint32_t blk = (uint32_t)(a / g.stride), n = blk_len(g, blk);
-        const uint32_t s = SA[a];
-        U[a] = T[(size_t)blk * g.stride + (s ? s - 1 : n - 1)];
-      }
-    }
-    return;
-  }
 #pragma unroll 4
   for (int it = 0; it < 16; it++) {
     const uint64_t a = (uint64_t)tile * RS_TILE + (uint32_t)it * 256 + threadIdx.x;
@@ -1364,12 +1263,9 @@ __global__ __launch_bounds__(256) void bwt_emit(const uint8_t* __restrict__ T, G
     const uint8_t* t = T + (size_t)blk * g.stride;
     uint8_t* u = U + (size_t)blk * g.stride;
     const uint32_t s = __builtin_nontemporal_load(SA + a);
-    if (cyclic) u[p] = t[s ? s - 1 : n - 1];
-    else {
-      const uint32_t p0 = R[(size_t)blk * g.stride];
-      if (p == p0) u[0] = t[n - 1];
-      else u[p < p0 ? p + 1 : p] = t[s - 1];
-    }
+    const uint32_t p0 = R[(size_t)blk * g.stride];
+    if (p == p0) u[0] = t[n - 1];
+    else u[p < p0 ? p + 1 : p] = t[s - 1];
   }
 }
 
@@ -1415,19 +1311,13 @@ static int radix_passes(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
   if (T > w.hist_tiles || sg.nseg > w.bintot_segs) return CJS_E_INVALID_ARG;
   K* kk[2] = {k0, k1}; uint32_t* vv[2] = {v0, v1};
   const GenSrc g0{nullptr, 0, 0, 0};
-  static const bool env_text_hist = getenv("CJS_R1_TEXT_HIST") == nullptr || atoi(getenv("CJS_R1_TEXT_HIST")) != 0;
   for (int shift = lo_bit; shift < hi_bit; shift += 8) {
     const bool first_gen = gen && shift == lo_bit;        // the first pass makes its keys from the block bytes
     const bool dig_out = dig && shift + 8 < hi_bit;          // a pass follows: leave its digits
     if (first_hist_ready && shift == lo_bit) {}
-    else if (dig && shift != lo_bit) {
-      static const int hb = getenv("CJS_HB_HR") ? atoi(getenv("CJS_HB_HR")) : 4;      // 100 M keys: 59-82 us per pass with 4 copies, 72-85 with 8, 75-130 with 2
-      if (hb == 2) hipLaunchKernelGGL(rs_hist_bytes<2>, dim3(T), dim3(256), 0, s, dig, sg, w.hist, 0u);
-      else if (hb == 4) hipLaunchKernelGGL(rs_hist_bytes<4>, dim3(T), dim3(256), 0, s, dig, sg, w.hist, 0u);
-      else hipLaunchKernelGGL(rs_hist_bytes<8>, dim3(T), dim3(256), 0, s, dig, sg, w.hist, 0u);
-    }
-    else if (first_gen && gen->cyclic && gen->packed && shift == PK_KEY_LO && env_text_hist)       // packed cyclic sort: the first digit is a text byte
-      hipLaunchKernelGGL(rs_hist_bytes<4>, dim3(T), dim3(256), 0, s, gen->T, sg, w.hist, gen->packed == 2 ? 6u : 4u);
+    else if (dig && shift != lo_bit) hipLaunchKernelGGL(rs_hist_bytes, dim3(T), dim3(256), 0, s, dig, sg, w.hist, 0u);
+    else if (first_gen && gen->cyclic && gen->packed && shift == PK_KEY_LO)       // packed cyclic sort: the first digit is the text byte at suffix + 6
+      hipLaunchKernelGGL(rs_hist_bytes, dim3(T), dim3(256), 0, s, gen->T, sg, w.hist, 6u);
     else if (first_gen) hipLaunchKernelGGL((rs_hist<K, true>), dim3(T), dim3(256), 0, s, kk[cur], sg, *gen, shift, w.hist, T);
     else hipLaunchKernelGGL((rs_hist<K, false>), dim3(T), dim3(256), 0, s, kk[cur], sg, g0, shift, w.hist, T);
     if (sg.tps <= 4 * SB_CHUNK) hipLaunchKernelGGL(rs_scan_bins, dim3(sg.nseg), dim3(256), 0, s, w.hist, sg.tps, w.bintot);
@@ -1462,28 +1352,17 @@ template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uin
 
 // Which tile sorter: the LDS radix version costs the same whatever the groups look like (18 ps per suffix), the counting /
 // bitonic version is cheaper once the groups are tiny (round 2 of the bench text, 7.7 suffixes per group: 1.51 vs 1.82 ms;
-// round 3, 3.5 per group: 0.67 vs 0.64 ms; later rounds up to 2x in favour of counting).  CJS_TILE_SORT=radix|count forces one.
-static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag, uint32_t ngroups, const TsGather* tg) {
-  static const int forced = !getenv("CJS_TILE_SORT") ? 0 : !strcmp(getenv("CJS_TILE_SORT"), "radix") ? 1 : 2;
-  const bool radix = forced ? forced == 1 : (ngroups && A / ngroups >= 5);
-  const TsGather t0{nullptr, nullptr, nullptr, 0u, 0, Geom{0u, 0u, 0u}};
-  if (radix) {
-    if (tg) hipLaunchKernelGGL(bwt_tile_sort_radix<true>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, *tg, Tt);
-    else hipLaunchKernelGGL(bwt_tile_sort_radix<false>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, t0, Tt);
-  } else {
-    if (tg) hipLaunchKernelGGL(bwt_tile_sort<true>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, *tg, Tt);
-    else hipLaunchKernelGGL(bwt_tile_sort<false>, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, t0, Tt);
-  }
+// round 3, 3.5 per group: 0.67 vs 0.64 ms; later rounds up to 2x in favour of counting).
+static void launch_tile_sort(hipStream_t s, uint32_t Tt, uint64_t* key, uint32_t* val, uint32_t A, uint8_t* dflag, uint32_t ngroups, const TsGather& tg) {
+  if (ngroups && A / ngroups >= 5) hipLaunchKernelGGL(bwt_tile_sort_radix, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, tg, Tt);
+  else hipLaunchKernelGGL(bwt_tile_sort, dim3(xcd_grid(Tt)), dim3(256), 0, s, key, val, A, dflag, tg, Tt);
 }
-// the tile sorters take the round (else: whole-array radix passes on keys that bwt_gather_keys has to write first)
-static bool tile_sorted_round(uint32_t A) {
-  static const bool no_tiles = getenv("CJS_NO_TILE_SORT") != nullptr;
-  return !no_tiles && A >= 2 * TS_WIN;
-}
+// the tile sorters take the round (small remainders: whole-array radix passes on keys that bwt_gather_keys writes first)
+static bool tile_sorted_round(uint32_t A) { return A >= 2 * TS_WIN; }
 // One sort of a round >= 2: in-LDS tile sort of the small groups + global radix passes for the large ones.
 // Works in place on (key[c], val[c]); only the whole-array fallback flips c.
-static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt, uint32_t ngroups, const TsGather* tg) {
-  if (!tile_sorted_round(A)) return radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, lt);
+static int sort_round(hipStream_t s, BwtWork& w, int& c, int pc, uint32_t A, int bits, LaunchTimes* lt, uint32_t ngroups, const TsGather& tg) {
+  if (!tile_sorted_round(A)) return radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, lt);      // (bwt_gather_keys made the keys)
   const uint32_t Tt = (A + TS_NOM - 1) / TS_NOM, Tg = (A + TS_GT - 1) / TS_GT;
   uint8_t* dflag = w.dflag;
   uint32_t* tcount = w.tile_cnt;                        // 3*cap/4096 entries >= cap/2048
@@ -1540,54 +1419,41 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
   const int blk_bits = bits_for(nb - 1);
   int nsym = segmented ? 7 : (64 - blk_bits) / sym_bits;
   if (nsym > 7) nsym = 7;
-  // packed round-1 records (5 bytes + position in one u64, no value array): cyclic, segmented sorts only
-  // defaults from same-box kernel-time A/Bs (profiles/r02_*): packed records + two-sweep rank scatter 18.60 -> 18.15 ms per step
-  static const bool env_packed = getenv("CJS_R1_PACKED") == nullptr || atoi(getenv("CJS_R1_PACKED")) != 0;
-  static const int env_halves = getenv("CJS_APPLY_HALVES") ? atoi(getenv("CJS_APPLY_HALVES")) : 3;      // 3: two launches without a counting pass, 2: one launch behind bwt_flags, 0: one sweep
-  // two-phase packed sort: bytes 2..6 first, then bytes 0..1 with the class of bytes 2..6 carried as a rank (depth 7)
-  // (same-box A/B: 17.9 -> 17.2 ms per step: the seven passes + the record rebuild cost 4.9 ms instead of 2.8, but 61 M instead of
-  //  83.5 M suffixes stay unresolved behind them and every suffix-round costs ~55 ps)
-  static const bool env_two_phase = getenv("CJS_R1_TWO_PHASE") == nullptr || atoi(getenv("CJS_R1_TWO_PHASE")) != 0;
-  // the scatter passes of the packed sort leave the next digit of every key as a byte for the next pass's counts (CJS_R1_DIG=0: counts from the keys)
-  static const bool env_dig = getenv("CJS_R1_DIG") == nullptr || atoi(getenv("CJS_R1_DIG")) != 0;
-  const bool packed = env_packed && segmented && cyclic;
-  const bool two_phase = packed && env_two_phase;
-  if (packed) nsym = two_phase ? 7 : 5;
+  // packed round-1 records (5 bytes + position in one u64, no value array) for cyclic, segmented sorts, as a two-phase sort:
+  // bytes 2..6 first, then bytes 0..1 with the class of bytes 2..6 carried as a rank (depth 7 at 8 bytes per record; same-box
+  // A/Bs in profiles/r02_*: the seven passes + the record rebuild cost more than five passes, but 61 M instead of 83.5 M suffixes
+  // stay unresolved behind them and every suffix-round costs ~55 ps).  The scatter passes leave the next digit of every key as a
+  // byte for the next pass's counts.  Everything else (sentinel form, unsegmented fallback): (u64 key, u32 value) records.
+  const bool packed = segmented && cyclic;
+  if (packed) nsym = 7;
   const SegGeom sg{nb, stride, n_last, tps};
-  const GenSrc gen{d_T, cyclic ? 1 : 0, nsym, packed ? (two_phase ? 2 : 1) : 0};
+  const GenSrc gen{d_T, cyclic ? 1 : 0, nsym, packed ? 2 : 0};
   if (!segmented) hipLaunchKernelGGL(bwt_init_keys, dim3(grid_lin), dim3(256), 0, s, d_T, g, (int)cyclic, nsym, M, w.key[0], w.val[0]);
   uint32_t A = M, h = (uint32_t)nsym, rounds = 0, ngroups = 0;
   w.no_large_groups = false;
   int bits = nsym * sym_bits + (segmented ? 0 : blk_bits);
   // two-sweep scheduling of the round-1 rank scatter (see HalfMap): pays only with the packed records (the second sweep of the
   // 12-byte key + value form re-reads more than the merged stores save: 2.15 vs 1.64 ms)
-  const bool sweeps = env_halves >= 2 && nb >= 8 && packed;
-  static const bool env_big = getenv("CJS_BIG_GROUP_TEST") == nullptr || atoi(getenv("CJS_BIG_GROUP_TEST")) != 0;
-  static const bool env_fuse = getenv("CJS_FUSE_GATHER") == nullptr || atoi(getenv("CJS_FUSE_GATHER")) != 0;
-  bool fuse = false;
+  const bool sweeps = nb >= 8 && packed;
   TsGather tg{nullptr, nullptr, nullptr, 0u, 0, g};
-  // cyclic form: the regroup kernels write the BWT bytes of the suffixes they resolve themselves (CJS_DIRECT_EMIT=0: suffix array + bwt_emit)
-  static const bool env_direct = getenv("CJS_DIRECT_EMIT") == nullptr || atoi(getenv("CJS_DIRECT_EMIT")) != 0;
-  const bool direct = cyclic && env_direct;
-  const uint8_t* dT = direct ? d_T : nullptr;
-  uint8_t* dU = direct ? d_U : nullptr;
-  const int gs1 = two_phase ? PK2_GSHIFT : packed ? PK_SHIFT : 0;      // group key of the round-1 records = key >> gs1
-  const int carried = two_phase && direct ? 1 : 0;                      // two-phase records (then val[]) carry the byte in front of their suffix
+  // cyclic form: the regroup kernels write the BWT bytes of the suffixes they resolve themselves; the sentinel form keeps a suffix array
+  const uint8_t* dT = cyclic ? d_T : nullptr;
+  uint8_t* dU = cyclic ? d_U : nullptr;
+  const int gs1 = packed ? PK2_GSHIFT : 0;                              // group key of the round-1 records = key >> gs1
+  const int carried = packed ? 1 : 0;                                   // packed records (then val[]) carry the byte in front of their suffix
   for (;;) {
     if (rounds == 0) {
       if (packed) {
-        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true, false, env_dig ? w.dflag : nullptr)));
-        if (two_phase) {
-          hipLaunchKernelGGL(bwt_phase2_records, dim3(sg.nseg * sg.tps), dim3(256), 0, s, w.key[c], sg, d_T, w.hist, w.key[1 - c]);
-          c = 1 - c;
-          CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true, true, env_dig ? w.dflag : nullptr)));
-        }
+        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, PK_KEY_LO, 64, &lt, &sg, &gen, true, false, w.dflag)));
+        hipLaunchKernelGGL(bwt_phase2_records, dim3(sg.nseg * sg.tps), dim3(256), 0, s, w.key[c], sg, d_T, w.hist, w.key[1 - c]);
+        c = 1 - c;
+        CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 48, 64, &lt, &sg, nullptr, true, true, w.dflag)));
       } else if (segmented) CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt, &sg, &gen)));
       else CJS_TRY((radix_passes<uint64_t>(s, w, w.key[0], w.val[0], w.key[1], w.val[1], c, A, 0, bits, &lt)));
-    } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups, fuse ? &tg : nullptr));
+    } else CJS_TRY(sort_round(s, w, c, pc, A, bits, &lt, ngroups, tg));
     const uint32_t T = (A + RS_TILE - 1) / RS_TILE;
-    if (rounds == 0 && packed && sweeps && env_halves == 3) {          // two launches, no counting pass (see bwt_apply)
-      const HalfMap hm{2u, 0u, stride};
+    if (rounds == 0 && sweeps) {                                       // two launches, no counting pass (see bwt_apply)
+      const HalfMap hm{2u, stride};
       hipLaunchKernelGGL((bwt_apply<true, true, 1>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                          w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4, gs1, carried);
       hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
@@ -1599,25 +1465,21 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     hipLaunchKernelGGL(bwt_scan_tiles, dim3(1), dim3(1024), 0, s, w.tile_cnt, T, w.counters, w.h_counters);
     CJS_HIP_TRY(hipEventRecord(w.ev_scan, s));
     if (rounds == 0) {
-      HalfMap hm{1u, 0u, stride};
-      uint32_t grid = xcd_grid(T);
-      if (sweeps) {
-        hm.halves = 2; hm.slots = (stride + RS_TILE - 1) / RS_TILE + 1;
-        grid = 8u * ((nb + 7u) / 8u) * 2u * hm.slots;
-      }
+      const HalfMap hm{1u, stride};
+      const uint32_t grid = xcd_grid(T);
       if (packed) hipLaunchKernelGGL((bwt_apply<true, true>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                                      w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4, gs1, carried);
       else hipLaunchKernelGGL((bwt_apply<true, false>), dim3(grid), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
                               w.val[1 - c], w.pos[1 - pc], w.gord, hm, dT, dU, w.counters + 4, gs1, carried);
     } else hipLaunchKernelGGL((bwt_apply<false, false>), dim3(xcd_grid(T)), dim3(256), 0, s, w.key[c], w.val[c], w.pos[pc], A, g, w.tile_cnt, T, w.R, w.SA,
-                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, 0u, stride}, dT, dU, w.counters + 4, gs1, carried);
+                              w.val[1 - c], w.pos[1 - pc], w.gord, HalfMap{1u, stride}, dT, dU, w.counters + 4, gs1, carried);
     }
     // the host only needs the counters of the tile scan: it waits for THAT kernel and queues the next round behind the regroup
     // kernel while it runs (a stream synchronisation here left the GPU idle for ~20 us per round)
     CJS_HIP_TRY(hipEventSynchronize(w.ev_scan));
     rounds++;
     const uint32_t A2 = w.h_counters[0], NG = w.h_counters[1];
-    if (w.h_counters[4] == 0 && env_big) w.no_large_groups = true;       // every group of the new grouping fits the tile sorters
+    if (w.h_counters[4] == 0) w.no_large_groups = true;       // every group of the new grouping fits the tile sorters
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwt] round %u h=%u A=%u bits=%d -> A'=%u groups=%u\n", rounds, h, A, bits, A2, NG);
     c = 1 - c; pc = 1 - pc;
     A = A2; ngroups = NG;
@@ -1627,8 +1489,7 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
       break;
     }
     if (rounds > 40) return CJS_E_HIP;    // cannot happen: depth doubles every round
-    fuse = env_fuse && tile_sorted_round(A);       // the tile sorters fetch the ranks themselves
-    if (fuse) tg = TsGather{w.R, w.pos[pc], w.gord, h, (int)cyclic, g};
+    if (tile_sorted_round(A)) tg = TsGather{w.R, w.pos[pc], w.gord, h, (int)cyclic, g};       // the tile sorters fetch the ranks themselves
     else {
       const uint32_t Tg = (A + RS_TILE - 1) / RS_TILE;
       hipLaunchKernelGGL(bwt_gather_keys, dim3(xcd_grid(Tg)), dim3(256), 0, s, g, (int)cyclic, A, h, w.R, w.val[c], w.pos[pc], w.gord, w.key[c], Tg);
@@ -1637,9 +1498,9 @@ int bwt_run(hipStream_t s, BwtWork& w, const uint8_t* d_T, uint32_t nb, uint32_t
     bits = 20 + bits_for(NG ? NG - 1 : 0);
   }
   hipLaunchKernelGGL(bwt_pidx, dim3(nb), dim3(256), 0, s, g, (int)cyclic, (int)(A != 0), w.R, d_pidx);
-  if (!direct) {
+  if (!cyclic) {
     const uint32_t Tn = (M + RS_TILE - 1) / RS_TILE;
-    hipLaunchKernelGGL(bwt_emit, dim3(xcd_grid(Tn)), dim3(256), 0, s, d_T, g, (int)cyclic, M, w.SA, w.R, d_U, Tn);
+    hipLaunchKernelGGL(bwt_emit_sentinel, dim3(xcd_grid(Tn)), dim3(256), 0, s, d_T, g, M, w.SA, w.R, d_U, Tn);
   }
   CJS_HIP_TRY(hipGetLastError());
   if (stats) stats->bwt_rounds = rounds;

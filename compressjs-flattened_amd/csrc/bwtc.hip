@@ -34,112 +34,6 @@ namespace cjs {
 constexpr uint32_t F_MAX = 0xFF00u, F_INC = 0x0100u;
 constexpr uint64_t STEP_SHIFT_FLAG = 1ull << 63;   // step is encodeShift(sy, lt, shift) instead of encodeFreq
 
-// ---------------------------------------------------------------- FenwickModel, one wave per block
-// tree lives in LDS; lane l owns level l of the leaf->root path.
-struct Fen {
-  uint32_t* tree; int num_syms;
-};
-// path sum + update (J/BWTC_joined_.js:1547-1562).  Returns lt (all lanes) and tot (old root).
-// lane l owns level l of the path; the <= 10 per-level contributions are summed with scalar readlanes.
-__device__ __forceinline__ void fen_path(const Fen& f, int leaf, uint32_t update, uint32_t& lt, uint32_t& tot) {
-  const int lane = lane_id();
-  const int node = lane < 16 ? leaf >> lane : 0;       // level `lane` of the path (0 when above the root)
-  uint32_t contrib = 0;
-  if (node > 1 && (node & 1)) contrib = f.tree[node - 1];
-  const uint32_t root = f.tree[1];
-  uint32_t sum = 0;
-#pragma unroll
-  for (int l = 0; l < 10; l++) sum += (uint32_t)__builtin_amdgcn_readlane((int)contrib, l);   // 2*num_syms <= 516 < 2^10
-  lt = sum;
-  tot = root;
-  if (node >= 1) f.tree[node] += update;
-  __builtin_amdgcn_wave_barrier();
-}
-__device__ void fen_sum_tree(const Fen& f) {           // _sumTree (:1655-1661), wave-parallel by index batches / levels
-  const int lane = lane_id();
-  int hi = f.num_syms - 1;
-  while (hi > 127) {                                   // no dependency inside a 64-wide batch when hi > 126
-    const int i = hi - lane;
-    if (i > 127) f.tree[i] = f.tree[2 * i] + f.tree[2 * i + 1];
-    __builtin_amdgcn_wave_barrier();
-    hi -= 64;
-    if (hi < 127) hi = 127;
-  }
-  for (int top = 64; top >= 1; top >>= 1) {            // levels [top, 2*top)
-    const int i = top + lane;
-    if (lane < top && i <= f.num_syms - 1) f.tree[i] = f.tree[2 * i] + f.tree[2 * i + 1];
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-__device__ void fen_rescale(const Fen& f) {            // _rescale (:1623-1654)
-  const int lane = lane_id();
-  bool esc_here = false;
-  for (int i = lane; i < f.num_syms - 1; i += 64) {
-    uint32_t prob = f.tree[f.num_syms + i];
-    if (prob & 0xFFFFu) { esc_here = true; continue; }
-    prob = (prob & 0xFFFEFFFEu) >> 1;
-    if (prob == 0) { prob = 1u; esc_here = true; }
-    f.tree[f.num_syms + i] = prob;
-  }
-  const bool no_escape = __ballot(esc_here) == 0ull;
-  if (lane == 0) {
-    uint32_t prob = f.tree[2 * f.num_syms - 1];
-    prob = (prob & 0xFFFEFFFEu) >> 1;
-    if (no_escape) prob = 0; else if (prob == 0) prob = 1u << 16;
-    f.tree[2 * f.num_syms - 1] = prob;
-  }
-  __builtin_amdgcn_wave_barrier();
-  fen_sum_tree(f);
-}
-// one coder step of encode() (:1530-1571): plain symbol, or symbol in the escape distribution (esc_ctx)
-__device__ __forceinline__ void fen_step(const Fen& f, int symbol, bool esc_ctx, uint64_t* out, uint32_t& n) {
-  const int leaf = f.num_syms + symbol;
-  const uint32_t sy_raw = f.tree[leaf];
-  uint32_t mask = 0xFFFF0000u; int shift = 16;
-  uint32_t update = F_INC << 16;
-  if (esc_ctx) { mask = 0x0000FFFFu; update -= 1u; shift = 0; }
-  else if (symbol == f.num_syms - 1 && (f.tree[1] & 0xFFFFu) == 1u) update = 0u - sy_raw;     // last escape: zero it out
-  uint32_t lt, tot;
-  fen_path(f, leaf, update, lt, tot);
-  if (lane_id() == 0)
-    out[n] = (uint64_t)((sy_raw & mask) >> shift) | ((uint64_t)((lt & mask) >> shift) << 16) | ((uint64_t)((tot & mask) >> shift) << 32);
-  n++;
-  if ((f.tree[1] >> 16) >= F_MAX) fen_rescale(f);
-}
-// encode(symbol): a symbol whose own count is still zero is announced by the escape symbol first (:1537-1541)
-__device__ __forceinline__ void fen_encode(const Fen& f, int symbol, uint64_t* out, uint32_t& n) {
-  const bool esc = (f.tree[f.num_syms + symbol] & 0xFFFF0000u) == 0;
-  if (esc) fen_step(f, f.num_syms - 1, false, out, n);
-  fen_step(f, symbol, esc, out, n);
-}
-
-__global__ __launch_bounds__(64) void bwtc_fenwick(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps) {
-  __shared__ uint32_t tree[520];
-  const uint32_t blk = blockIdx.x;
-  const uint32_t asz = mb.asz[blk], nsym = mb.npos[blk] - 1;      // drop bzip2's EOB
-  const uint16_t* A = mb.A + (size_t)blk * mb.a_stride;
-  uint64_t* out = steps + (size_t)blk * step_stride;
-  const int lane = lane_id();
-  Fen f{tree, (int)asz + 2};
-  const int size = (int)asz + 1;
-  for (int i = lane; i < 2 * f.num_syms; i += 64) tree[i] = 0;
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < size; i += 64) tree[f.num_syms + i] = 1u;
-  if (lane == 0) tree[f.num_syms + size] = F_INC << 16;
-  __builtin_amdgcn_wave_barrier();
-  fen_sum_tree(f);
-  uint32_t n = 0;
-  for (uint32_t base = 0; base < nsym; base += 64) {
-    const uint32_t mine = base + lane < nsym ? A[base + lane] : 0u;
-    const uint32_t cnt = nsym - base < 64 ? nsym - base : 64;
-    for (uint32_t j = 0; j < cnt; j++) {
-      const int sym = __builtin_amdgcn_readlane((int)mine, (int)j);
-      fen_encode(f, sym, out, n);
-    }
-  }
-  if (lane == 0) nsteps[blk] = n;
-}
-
 // ---------------------------------------------------------------- FenwickModel evaluated 64 symbols at a time
 // Between two rescales the model only counts: every coded symbol adds F_INC to its own frequency, and a symbol whose
 // frequency is zero is announced by the escape symbol first.  So for a chunk of 64 symbols with NO rescale inside,
@@ -223,7 +117,7 @@ __device__ void fm_serial(uint32_t* leaf, uint32_t* cum, int ns, int e, int symb
 // baton (an LDS ticket), runs the state part of its chunk on the shared leaf array and passes the baton on.  A lone wave
 // issues about one instruction per 8 cycles, so the block's critical path shrinks to the state parts alone.
 constexpr int FP_WAVES = 8;
-__global__ __launch_bounds__(64 * FP_WAVES) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps, int force_serial) {
+__global__ __launch_bounds__(64 * FP_WAVES) void bwtc_fenwick_par(MtfBufs mb, uint64_t* __restrict__ steps, size_t step_stride, uint32_t* __restrict__ nsteps) {
   __shared__ uint32_t leaf[328], cum[328];
   __shared__ uint32_t turn_s, n_s;           // next chunk whose state part may run; coder steps emitted so far
   const uint32_t blk = blockIdx.x;
@@ -277,9 +171,9 @@ __global__ __launch_bounds__(64 * FP_WAVES) void bwtc_fenwick_par(MtfBufs mb, ui
       const uint32_t through = rel + 1u + Eb + (escj ? 1u : 0u);                             // steps up to and including this position
       const uint32_t root_hi = root >> 16, root_lo = root & 0xFFFFu;
       const uint32_t kstar = root_hi >= F_MAX ? 1u : (F_MAX - root_hi + F_INC - 1u) / F_INC;  // the step after which the total reaches F_MAX
-      const bool cut = active && (through >= kstar || (escj && (root_lo - Eb == 1u || (force_serial & 2))));
+      const bool cut = active && (through >= kstar || (escj && root_lo - Eb == 1u));
       const uint64_t cutm = __ballot(cut);
-      const uint32_t c = (force_serial & 1) ? start : cutm ? (uint32_t)__builtin_ctzll(cutm) : cnt;                       // [start, c) in parallel, c one at a time
+      const uint32_t c = cutm ? (uint32_t)__builtin_ctzll(cutm) : cnt;                       // [start, c) in parallel, c one at a time
       const uint64_t parw = win & (c == 64 ? ~0ull : ((1ull << c) - 1ull));
       if ((parw >> lane) & 1ull) {
         const uint32_t tot = root_hi + F_INC * (rel + Eb);
@@ -652,7 +546,18 @@ struct BwtcJob {
   bool abort = false;
 };
 
+void bwtc_batch_body(BwtcJob* J, BwtcBatch* B);
+// nothing may leave a worker thread (std::terminate): an exception becomes the batch's return code and stops the job
 void bwtc_batch_worker(BwtcJob* J, BwtcBatch* B) {
+  int rc = 0;
+  try { bwtc_batch_body(J, B); return; }
+  catch (const std::bad_alloc&) { rc = CJS_E_OUT_OF_MEMORY; }
+  catch (...) { rc = CJS_E_HIP; }
+  std::lock_guard<std::mutex> lk(J->mu);
+  B->rc = rc; B->done = true; J->abort = true;
+  J->cv.notify_all();
+}
+void bwtc_batch_body(BwtcJob* J, BwtcBatch* B) {
   {
     std::unique_lock<std::mutex> lk(J->mu);
     J->cv.wait(lk, [&] { return J->abort || (J->next_seq[B->slot] == B->seq && J->live[B->slot] < 2); });
@@ -694,28 +599,8 @@ void bwtc_batch_worker(BwtcJob* J, BwtcBatch* B) {
   if (!rc) rc = mtf_run(s, mw, d_U, cnt, d_len);
   if (!rc) {
     if (J->fast) hipLaunchKernelGGL(bwtc_defsum, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps);
-    else if (getenv("CJS_BWTC_SERIAL_MODEL")) hipLaunchKernelGGL(bwtc_fenwick, dim3(cnt), dim3(64), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps);
-    else hipLaunchKernelGGL(bwtc_fenwick_par, dim3(cnt), dim3(64 * FP_WAVES), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps, getenv("CJS_BWTC_FORCE_SERIAL") ? atoi(getenv("CJS_BWTC_FORCE_SERIAL")) : 0);
+    else hipLaunchKernelGGL(bwtc_fenwick_par, dim3(cnt), dim3(64 * FP_WAVES), 0, s, mw.b, B->d_steps, B->step_stride, d_nsteps);
     if (hipGetLastError() != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && !J->fast && getenv("CJS_BWTC_CHECK")) {               // debug: the one-symbol-at-a-time kernel must give the same steps
-      uint64_t* d_ref = nullptr; uint32_t* d_nref = nullptr;
-      if (hipMalloc((void**)&d_ref, 8 * (size_t)cnt * B->step_stride) == hipSuccess && hipMalloc((void**)&d_nref, 4 * (size_t)cnt) == hipSuccess) {
-        hipLaunchKernelGGL(bwtc_fenwick, dim3(cnt), dim3(64), 0, s, mw.b, d_ref, B->step_stride, d_nref);
-        std::vector<uint32_t> na(cnt), nr(cnt);
-        (void)hipMemcpyAsync(na.data(), d_nsteps, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s);
-        (void)hipMemcpyAsync(nr.data(), d_nref, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
-        for (uint32_t k = 0; k < cnt; k++) {
-          const uint32_t m = na[k] < nr[k] ? na[k] : nr[k];
-          std::vector<uint64_t> x(m), r(m);
-          if (m) { (void)hipMemcpy(x.data(), B->d_steps + (size_t)k * B->step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); (void)hipMemcpy(r.data(), d_ref + (size_t)k * B->step_stride, 8 * (size_t)m, hipMemcpyDeviceToHost); }
-          uint32_t i = 0; while (i < m && x[i] == r[i]) i++;
-          if (i < m || na[k] != nr[k]) { fprintf(stderr, "[cjs bwtc check] block %u: steps %u vs %u, first difference at %u\n", B->first + k, na[k], nr[k], i); break; }
-        }
-      }
-      if (d_ref) (void)hipFree(d_ref);
-      if (d_nref) (void)hipFree(d_nref);
-    }
   }
   B->pidx.resize(cnt); B->asz.resize(cnt); B->nsteps.resize(cnt); B->alist.resize((size_t)cnt * 256);
   if (!rc && hipMemcpyAsync(B->pidx.data(), d_pidx, 4 * (size_t)cnt, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
@@ -786,7 +671,21 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
         k += c;
       }
     }
-    std::vector<std::thread> workers;
+    // on every path out of this scope (an exception of the coder side included: out.resize in reserve_steps) the workers are
+    // stopped and joined, the batches give their device memory back and the pinned step buffers are freed
+    struct Workers {
+      BwtcJob& J; int dev0; std::vector<std::thread> th; uint64_t* h_buf[2] = {nullptr, nullptr};
+      ~Workers() {
+        bool running = false;
+        for (auto& t : th) running |= t.joinable();
+        if (running) { { std::lock_guard<std::mutex> lk(J.mu); J.abort = true; } J.cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); }
+        for (auto& B : J.batches) B.release();
+        (void)hipSetDevice(dev0);
+        for (int q = 0; q < 2; q++) if (h_buf[q]) (void)hipHostFree(h_buf[q]);
+      }
+    } wk{J, dev0};
+    std::vector<std::thread>& workers = wk.th;
+    uint64_t** h_buf = wk.h_buf;
     for (auto& B : J.batches) workers.emplace_back(bwtc_batch_worker, &J, &B);
     // reciprocals floor(2^64 / tot) + 1 for every total a step can carry (17 bits); tot < 2 keeps the division
     static std::vector<uint64_t> rcp;
@@ -794,7 +693,6 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     std::call_once(rcp_once, [] { rcp.assign(1u << 17, 0ull); for (uint32_t t = 2; t < (1u << 17); t++) rcp[t] = (uint64_t)(((unsigned __int128)1 << 64) / t) + 1; });
     // the steps of block k+1 travel (pinned buffer, copy stream of its batch) while block k goes through the coder
     const size_t step_stride = 2 * MtfWork::a_stride_for(bs);
-    uint64_t* h_buf[2] = {nullptr, nullptr};
     if (hipHostMalloc((void**)&h_buf[0], 8 * step_stride, hipHostMallocPortable) != hipSuccess || hipHostMalloc((void**)&h_buf[1], 8 * step_stride, hipHostMallocPortable) != hipSuccess) rc = CJS_E_HIP;
     size_t bi_of_next = 0;                                           // batch that holds the next block to fetch
     hipEvent_t pending[2] = {nullptr, nullptr}; int pending_dev[2] = {0, 0};
@@ -864,9 +762,7 @@ extern "C" int cjs_bwtc_compress(const uint8_t* in, size_t n, int level, uint8_t
     if (rc) { std::lock_guard<std::mutex> lk(J.mu); J.abort = true; J.cv.notify_all(); }
     for (auto& t : workers) t.join();
     double ms_gpu_max = 0;
-    for (auto& B : J.batches) { if (!rc && B.rc) rc = B.rc; ms_gpu_max = std::max(ms_gpu_max, B.ms); B.release(); }
-    (void)hipSetDevice(dev0);
-    for (int q = 0; q < 2; q++) if (h_buf[q]) (void)hipHostFree(h_buf[q]);
+    for (auto& B : J.batches) { if (!rc && B.rc) rc = B.rc; ms_gpu_max = std::max(ms_gpu_max, B.ms); }
     if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs bwtc] %zu batch(es) on %u slot(s): first step list after %.1f ms, longest batch (workspace + H2D + BWT + MTF + model) %.1f ms, "
                                              "range coder over the step lists (host, serial) %.1f ms, coder waited for the GPU %.1f ms, total %.1f ms\n",
                                      J.batches.size(), (unsigned)J.live.size(), ms_first, ms_gpu_max, ms_coder, ms_stall, since(T0));

@@ -94,10 +94,15 @@ struct BitReader {
   __device__ __forceinline__ uint32_t get(int k) { const uint32_t v = peek(k); skip(k); return v; }
 };
 
+// Canonical code of one table in first-code form: the codes of length L are first[L] .. first[L] + cnt[L] - 1, handed out in
+// symbol order (bysym[start[L] ..]), and first[L + 1] = (first[L] + cnt[L]) << 1.  A prefix j of L bits that is not a code of a
+// shorter length satisfies j >= first[L], so "j - first[L] < cnt[L]" decides -- the same decisions as the reference's
+// limit / base / permute walk (:1522-1581, :1605-1616) on every length table, complete or not.
 struct DecShared {
-  uint32_t limit[6][22];
-  uint32_t base[6][22];
-  uint16_t permute[6][260];
+  uint32_t first[6][22];           // first code of each length
+  uint16_t cnt[6][22];             // symbols of each length
+  uint16_t start[6][22];           // index of the first symbol of each length in bysym
+  uint16_t bysym[6][260];          // symbols ordered by (length, symbol)
   uint16_t fast[6][1024];          // (sym << 5) | len, 0 = not decodable within 10 bits
   uint8_t minlen[8], maxlen[8];
   uint8_t length[6][260];
@@ -191,42 +196,30 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   const uint32_t sym_count = sym_total + 2;
   __builtin_amdgcn_wave_barrier();
   if (!err) {
-    // limit / base / permute (:1522-1581): lane g builds group g
+    // canonical tables: lane g builds table g -- a counting sort of the symbols by length, then the first codes
     if ((uint32_t)lane < group_count) {
       const int g = lane;
-      int mn = S.length[g][0], mx = S.length[g][0];
-      for (uint32_t i = 1; i < sym_count; i++) { const int l = S.length[g][i]; if (l > mx) mx = l; else if (l < mn) mn = l; }
+      for (int i = 0; i < 22; i++) { S.cnt[g][i] = 0; S.first[g][i] = 0; S.start[g][i] = 0; }
+      int mn = 20, mx = 1;
+      for (uint32_t i = 0; i < sym_count; i++) { const int l = S.length[g][i]; S.cnt[g][l]++; mn = l < mn ? l : mn; mx = l > mx ? l : mx; }
       S.minlen[g] = (uint8_t)mn; S.maxlen[g] = (uint8_t)mx;
-      int pp = 0; uint16_t temp[21];
-      for (int i = 0; i < 21; i++) temp[i] = 0;
-      for (int i = mn; i <= mx; i++) for (uint32_t s = 0; s < sym_count; s++) if (S.length[g][s] == i) S.permute[g][pp++] = (uint16_t)s;
-      for (uint32_t i = 0; i < sym_count; i++) temp[S.length[g][i]]++;
-      for (int i = 0; i < 22; i++) { S.limit[g][i] = 0; S.base[g][i] = 0; }
-      long long p2 = 0, t2 = 0;
-      for (int i = mn; i < mx; i++) {
-        p2 += temp[i];
-        S.limit[g][i] = (uint32_t)(p2 - 1);
-        p2 <<= 1;
-        t2 += temp[i];
-        S.base[g][i + 1] = (uint32_t)(p2 - t2);
+      uint32_t code = 0, at = 0; uint16_t fillp[22];
+      for (int l = mn; l <= mx; l++) {
+        S.first[g][l] = code; S.start[g][l] = (uint16_t)at; fillp[l] = (uint16_t)at;
+        at += S.cnt[g][l];
+        code = (code + S.cnt[g][l]) << 1;
       }
-      S.limit[g][mx] = (uint32_t)(p2 + temp[mx] - 1);
-      S.base[g][mn] = 0;
+      for (uint32_t i = 0; i < sym_count; i++) S.bysym[g][fillp[S.length[g][i]]++] = (uint16_t)i;
     }
     __builtin_amdgcn_wave_barrier();
-    // 10-bit direct tables from the same decode rule (:1605-1616)
+    // 10-bit direct tables: entry x = the code that is a prefix of the 10 bits x, if it has one of <= 10 bits
     for (uint32_t g = 0; g < group_count; g++) {
       const int mn = S.minlen[g], mx = S.maxlen[g];
       for (int x = lane; x < 1024; x += 64) {
         uint16_t e = 0;
         for (int i = mn; i <= 10 && i <= mx; i++) {
-          const uint32_t j = (uint32_t)x >> (10 - i);
-          if (j <= S.limit[g][i]) {
-            const long long jj = (long long)j - (long long)S.base[g][i];
-            if (jj >= 0 && jj < 258) e = (uint16_t)((S.permute[g][jj] << 5) | i);
-            else e = 0x1F;                                   // decodes, but to an out-of-range index: DATA_ERROR
-            break;
-          }
+          const uint32_t k = ((uint32_t)x >> (10 - i)) - S.first[g][i];      // (not below first: no shorter code matched)
+          if (k < S.cnt[g][i]) { e = (uint16_t)((S.bysym[g][S.start[g][i] + k] << 5) | i); break; }
         }
         S.fast[g][x] = e;
       }
@@ -242,212 +235,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
 
 __device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
 #define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
-// ---------------------------------------------------------------- 2b. the same decode as a two-wave pipeline
-// A lone wave issues about one instruction every 8 cycles and a block is one dependent chain of ~650 k symbols, so the
-// chain is cut in two stages that run on different SIMDs of the CU:
-//   wave 0 (producer): Huffman codes -> symbols (table lookups for 64 bit positions at once + readlane chain, as above);
-//                      the symbols of a round are collected in a register (one lane each) and leave as ONE LDS store;
-//   wave 1 (consumer): RUNA/RUNB + move-to-front + output bytes, reading up to 64 symbols per LDS load.
-// They share a ring of symbols in LDS; the cursors are workgroup-scope atomics.  Every wait loop also watches the
-// other side's stop flag, so both waves always reach the final barrier.
-constexpr uint32_t PIPE_RING = 2048;          // symbols
-constexpr uint32_t PIPE_EOB = 0xFFFFu;
-struct PipeShared {
-  uint16_t ring[PIPE_RING];
-  uint32_t wr, rd;                            // symbols produced / consumed
-  uint32_t stop;                              // bit 0: producer finished (EOB or error), bit 1: consumer aborted
-  int32_t perr, cerr;                         // error codes of the two sides
-  uint32_t sym_total, orig, crc, count;
-  uint64_t end_bit;
-};
-__global__ __launch_bounds__(128) void bz_decode_block_pipe(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand,
-                                                            uint32_t dbuf_size, uint8_t* __restrict__ tt_all, BlockOut* __restrict__ outs) {
-  __shared__ DecShared S;
-  __shared__ PipeShared P;
-  const uint32_t c = blockIdx.x;
-  if (c >= ncand) return;
-  const int lane = lane_id();
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (cands[c].kind != 0) {
-    if (threadIdx.x == 0) { BlockOut bo; bo.end_bit = cands[c].bit + 48; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0; outs[c] = bo; }
-    return;
-  }
-  uint8_t* tt = tt_all + (size_t)cands[c].pad * dbuf_size;
-  uint32_t group_count = 0, n_sel = 0;
-  uint64_t pos = 0;
-  if (wv == 0) {
-    BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
-    uint32_t crc = 0, orig = 0, sym_total = 0;
-    const int err = dec_prologue(S, r, dbuf_size, crc, orig, sym_total, group_count, n_sel);
-    pos = r.pos;
-    if (lane == 0) { P.wr = 0; P.rd = 0; P.stop = 0; P.perr = err; P.cerr = 0; P.sym_total = sym_total; P.orig = orig; P.crc = crc; P.count = 0; P.end_bit = r.pos; }
-  }
-  __syncthreads();
-  const int err0 = __builtin_amdgcn_readfirstlane(P.perr);
-  const uint32_t sym_total = __builtin_amdgcn_readfirstlane(P.sym_total);
-  if (!err0) {
-    if (wv == 0) {
-      // ---------------- producer
-      BitWin bw{in, n, 0, 0, 0};
-      bw.init(pos, lane);
-      int err = 0;
-      uint32_t selector = 0, sym_left = 0, wr = 0, rd_seen = 0; int g = 0;
-      uint32_t dbg_full = 0, dbg_rounds = 0;
-      const uint64_t t_p0 = wall_clock64();
-      bool done = false;
-      while (!done && !err) {
-        if (sym_left == 0) {
-          sym_left = 50;
-          if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
-          g = __builtin_amdgcn_readfirstlane((int)S.selectors[selector++]);
-          if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
-        }
-        bw.ensure(pos, lane);
-        uint32_t e;
-        {
-          const uint32_t d = (uint32_t)((pos >> 5) - bw.base);
-          const uint32_t w0 = bw.word(d), w1 = bw.word(d + 1), w2 = bw.word(d + 2), w3 = bw.word(d + 3);
-          const uint32_t o = (uint32_t)(pos & 31) + (uint32_t)lane, wi = o >> 5;
-          const uint32_t hi = wi == 0 ? w0 : wi == 1 ? w1 : w2, lo = wi == 0 ? w1 : wi == 1 ? w2 : w3;
-          const uint32_t x = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31)) >> 54);
-          e = S.fast[g][x];
-        }
-        uint32_t idx = 0, cnt = 0, symv = 0;
-        do {
-          uint32_t ee = __builtin_amdgcn_readlane(e, idx);
-          if (__builtin_expect(ee == 0u || ee == 0x1Fu, 0)) {
-            if (ee) { err = CJS_E_DATA_ERROR; break; }
-            const uint64_t p0 = pos + idx;                     // long code: the reference's bit-by-bit rule
-            int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);
-            const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
-            long long j = bw.peek(p0, i);
-            for (;; i++) {
-              if (i > mx) { err = CJS_E_DATA_ERROR; break; }
-              if (j <= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
-              j = (j << 1) | bw.peek(p0 + i, 1);
-            }
-            if (err) break;
-            j -= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.base[g][i]);
-            if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
-            ee = (__builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]) << 5) | (uint32_t)i;
-          }
-          uint32_t sym = ee >> 5;
-          idx += ee & 31u; sym_left--;
-          if (sym > sym_total) { sym = PIPE_EOB; done = true; }
-          symv = (uint32_t)lane == cnt ? sym : symv;               // lane cnt keeps the symbol (v_writelane would need m0)
-          cnt++;
-        } while (!done && idx < 64 && sym_left);
-        pos += idx;
-        if (cnt) {
-          // room for this round?  (the consumer's cursor is re-read only when the cached one says "full")
-          while (wr + cnt - rd_seen > PIPE_RING) {
-            rd_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.rd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));     // uniform, and known to be
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & 2u) { done = true; cnt = 0; break; }
-            if (wr + cnt - rd_seen > PIPE_RING) { dbg_full++; __builtin_amdgcn_s_sleep(2); }
-          }
-          if ((uint32_t)lane < cnt) P.ring[(wr + lane) & (PIPE_RING - 1)] = (uint16_t)symv;
-          wr += cnt; dbg_rounds++;
-          if (lane == 0) __hip_atomic_store(&P.wr, wr, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      if (lane == 0 && blockIdx.x == 0) { g_dec_clk[4] = dbg_full; g_dec_clk[5] = dbg_rounds; g_dec_clk[6] = wall_clock64() - t_p0; g_dec_clk[7] = wr; }
-      if (lane == 0) {
-        P.perr = err;
-        P.end_bit = pos > n * 8 ? n * 8 : pos;
-        __hip_atomic_fetch_or(&P.stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    } else {
-      // ---------------- consumer
-      uint32_t L = 0;
-#pragma unroll
-      for (int b = 0; b < 4; b++) L |= (uint32_t)S.sym_to_byte[4 * lane + b] << (8 * b);
-      const int lane4m1 = 4 * lane - 1;
-      uint32_t outb = 0, obase = 0, dbuf_count = 0, run_bit = 0, run_t = 0, rd = 0;
-      uint32_t dbg_empty = 0, dbg_batches = 0;
-      const uint64_t t_c0 = wall_clock64();
-      int err = 0;
-      bool done = false;
-      while (!done && !err) {
-        const uint32_t wr = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.wr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (wr == rd) {
-          if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) & 1u) {
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&P.wr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == rd) break;    // producer stopped without EOB (its error)
-            continue;
-          }
-          dbg_empty++;
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        dbg_batches++;
-        const uint32_t navail = wr - rd, nb_ = navail < 64u ? navail : 64u;
-        const uint32_t symv = (uint32_t)lane < nb_ ? (uint32_t)P.ring[(rd + lane) & (PIPE_RING - 1)] : 0u;
-        // structured control flow only (no break/continue): every early exit would make the compiler thread a state
-        // variable through the loop nest, which costs this lone wave more than the work itself
-        uint32_t stopc = 0;                                    // 1 = EOB, 2 = data error
-        dbuf_count = __builtin_amdgcn_readfirstlane(dbuf_count); obase = __builtin_amdgcn_readfirstlane(obase);      // (tell the compiler: uniform)
-        run_t = __builtin_amdgcn_readfirstlane(run_t); run_bit = __builtin_amdgcn_readfirstlane(run_bit);
-        for (uint32_t rr = 0; rr < nb_ && !stopc; rr++) {
-          const uint32_t next_sym = __builtin_amdgcn_readlane(symv, rr);
-          if (next_sym <= 1) {                                 // RUNA / RUNB
-            run_t += (next_sym + 1u) << run_bit;
-            run_bit++;
-            stopc = run_bit >= 20 ? 2u : 0u;
-          } else {
-            if (run_bit) {
-              run_bit = 0;
-              if (dbuf_count + run_t > dbuf_size) stopc = 2;
-              else {
-                const uint8_t uc = (uint8_t)(__builtin_amdgcn_readlane(L, 0) & 0xFFu);
-                if ((uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;       // pending singles first
-                for (uint32_t q = lane; q < run_t; q += 64) tt[dbuf_count + q] = uc;
-                dbuf_count += run_t;
-                obase = dbuf_count;
-                run_t = 0;
-              }
-            }
-            if (next_sym == PIPE_EOB) stopc |= 1u;
-            else if (dbuf_count >= dbuf_size) stopc = 2;
-            else if (!stopc) {
-              const uint32_t k = next_sym - 1;
-              const uint32_t v = (__builtin_amdgcn_readlane(L, k >> 2) >> (8u * (k & 3u))) & 0xFFu;
-              const uint32_t vv = v << 24;
-              const uint32_t up = __builtin_amdgcn_update_dpp(vv, L, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-              const uint32_t shifted = __builtin_amdgcn_alignbit(L, up, 24);
-              int nb = (int)k - lane4m1;
-              nb = nb < 0 ? 0 : nb > 4 ? 4 : nb;
-              const uint32_t m = (uint32_t)((1ull << (8 * nb)) - 1ull);
-              L = (shifted & m) | (L & ~m);
-              const uint32_t slot = dbuf_count - obase;
-              outb = (uint32_t)lane == slot ? v : outb;
-              dbuf_count++;
-              if (slot == 63) { tt[obase + lane] = (uint8_t)outb; obase = dbuf_count; }
-            }
-          }
-        }
-        if (stopc & 2u) err = CJS_E_DATA_ERROR;
-        else if (stopc & 1u) done = true;
-        rd += nb_;
-        if (lane == 0) __hip_atomic_store(&P.rd, rd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (!err && done && (uint32_t)lane < dbuf_count - obase) tt[obase + lane] = (uint8_t)outb;
-      if (lane == 0 && blockIdx.x == 0) { g_dec_clk[0] = dbg_empty; g_dec_clk[1] = dbg_batches; g_dec_clk[2] = wall_clock64() - t_c0; }
-      if (lane == 0) {
-        P.cerr = err; P.count = dbuf_count;
-        if (err) __hip_atomic_fetch_or(&P.stop, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    BlockOut bo;
-    int err = P.perr ? P.perr : P.cerr;
-    if (!err && P.orig >= P.count) err = CJS_E_DATA_ERROR;      // :1677
-    bo.end_bit = P.end_bit; bo.count = P.count; bo.orig = P.orig; bo.crc = P.crc; bo.err = err;
-    outs[c] = bo;
-  }
-}
-
-// ---------------------------------------------------------------- 2c. block decode in three stages (default)
+// ---------------------------------------------------------------- 2b. block decode in three stages
 // The Huffman chain of a block is serial (the table changes every 50 symbols, so there is no self-synchronisation to
 // exploit), but nothing BEHIND it has to be:
 //   bz_huff_ops     one wave per candidate follows the code chain (64 table lookups per round + readlane hops) and keeps
@@ -492,14 +280,14 @@ __device__ __forceinline__ int huff_flush(uint32_t sd, uint32_t fill, int lane, 
 constexpr uint32_t MT_TILE = 256;
 __global__ __launch_bounds__(64) void bz_huff_ops(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
                                                   uint8_t* __restrict__ ops_all, uint32_t* __restrict__ opoff_all, uint32_t ops_stride,
-                                                  uint8_t* __restrict__ l0_all, uint32_t* __restrict__ nops_all, BlockOut* __restrict__ outs) {
+                                                  uint8_t* __restrict__ l0_all, uint32_t* __restrict__ nops_all, BlockOut* __restrict__ outs, uint32_t row0) {
   __shared__ DecShared S;
   const uint32_t c = blockIdx.x;
   if (c >= ncand) return;
   const int lane = lane_id();
   BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
   if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
-  const uint32_t row = cands[c].pad;
+  const uint32_t row = cands[c].pad - row0;              // row of this batch's scratch
   uint8_t* ops = ops_all + (size_t)row * ops_stride;
   uint32_t* opoff = opoff_all + (size_t)row * ops_stride;
   BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
@@ -538,7 +326,7 @@ __global__ __launch_bounds__(64) void bz_huff_ops(const uint8_t* __restrict__ in
         const uint32_t x = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31)) >> 54);
         const uint32_t e = S.fast[g][x];
         len_l = e & 31u; sym_l = e >> 5;
-        const uint32_t step = (e == 0u || e == 0x1Fu) ? 64u : len_l;      // a code the 10-bit table cannot decode ends the walk
+        const uint32_t step = e == 0u ? 64u : len_l;                       // a code the 10-bit table cannot decode ends the walk
         uint32_t idx = 0;
         do {                                                             // the serial chain: code start -> next code start
           mask |= 1ull << idx;
@@ -552,18 +340,17 @@ __global__ __launch_bounds__(64) void bz_huff_ops(const uint8_t* __restrict__ in
         if (stl == 64u) { mask &= ~(1ull << ll); adv = ll; slow = true; }
         else adv = ll + stl;
       } else {
-        int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);            // long code: the reference's bit-by-bit rule (:1605-1616)
+        int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);            // a code of more than 10 bits: one bit at a time (the decisions of :1605-1616)
         const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
-        long long j = bw.peek(pos, i);
+        uint32_t j = bw.peek(pos, i), k = 0;
         for (;; i++) {
-          if (i > mx) { err = CJS_E_DATA_ERROR; break; }
-          if (j <= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.limit[g][i])) break;
+          if (i > mx) { err = CJS_E_DATA_ERROR; break; }                       // no code of this table starts here
+          k = j - (uint32_t)__builtin_amdgcn_readfirstlane(S.first[g][i]);
+          if (k < (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)S.cnt[g][i])) break;
           j = (j << 1) | bw.peek(pos + i, 1);
         }
         if (err) break;
-        j -= (long long)(uint32_t)__builtin_amdgcn_readfirstlane(S.base[g][i]);
-        if (j < 0 || j >= 258) { err = CJS_E_DATA_ERROR; break; }
-        sym_l = __builtin_amdgcn_readfirstlane((uint32_t)S.permute[g][j]);
+        sym_l = __builtin_amdgcn_readfirstlane((uint32_t)S.bysym[g][(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)S.start[g][i]) + k]);
         len_l = (uint32_t)i; mask = 1ull; adv = (uint32_t)i; slow = false;
       }
       // end of block inside this round?  (:1640)  symbols behind it are not symbols
@@ -685,9 +472,18 @@ __global__ __launch_bounds__(256) void bz_mtf_emit(const uint8_t* __restrict__ q
   }
 }
 
+// decoded rows of a batch -> their packed places (phase A with several batches): desc[row] = destination address | count << 44
+__global__ __launch_bounds__(256) void bz_rows_pack(const uint8_t* __restrict__ rows, uint32_t stride, const uint64_t* __restrict__ desc) {
+  const uint64_t d = desc[blockIdx.y];
+  uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(d & ((1ull << 44) - 1ull));
+  const uint32_t cnt = (uint32_t)(d >> 44);
+  const uint8_t* __restrict__ src = rows + (size_t)blockIdx.y * stride;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // ---------------------------------------------------------------- 4. inverse BWT
 struct IbBlock {            // per valid block, in stream order
-  uint32_t cand;            // candidate index (tt / hist location)
+  uint64_t tt;              // device address of the block's decoded BWT bytes
   uint32_t count;           // n
   uint32_t orig;
   uint32_t off;             // element offset of the block in the concatenated arrays
@@ -697,30 +493,30 @@ struct IbBlock {            // per valid block, in stream order
 };
 
 // keys (block << 8 | byte), vals = i
-__global__ __launch_bounds__(256) void ib_make_keys(const uint8_t* __restrict__ tt_all, uint32_t dbuf_size, const IbBlock* __restrict__ blocks,
-                                                    uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+__global__ __launch_bounds__(256) void ib_make_keys(const IbBlock* __restrict__ blocks, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
   const IbBlock b = blocks[blockIdx.y];
+  const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < b.count; i += gridDim.x * 256) {
-    key[b.off + i] = ((uint32_t)blockIdx.y << 8) | tt_all[(size_t)b.cand * dbuf_size + i];
+    key[b.off + i] = ((uint32_t)blockIdx.y << 8) | tt[i];
     val[b.off + i] = i;
   }
 }
 // after the stable sort: slot j of the block holds (T[j] << 8) | tt[j] == the reference's dbuf (:1686-1690):
 // the pointer comes from the sorted order, the low byte is the j-th DECODED byte (not the sorted one)
-__global__ __launch_bounds__(256) void ib_pack(const uint8_t* __restrict__ tt_all, uint32_t dbuf_size, const IbBlock* __restrict__ blocks,
-                                               const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf) {
+__global__ __launch_bounds__(256) void ib_pack(const IbBlock* __restrict__ blocks, const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf) {
   const IbBlock b = blocks[blockIdx.y];
+  const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < b.count; j += gridDim.x * 256)
-    dbuf[b.off + j] = (val[b.off + j] << 8) | tt_all[(size_t)b.cand * dbuf_size + j];
+    dbuf[b.off + j] = (val[b.off + j] << 8) | tt[j];
 }
 // sentinel variant (BWT.unbwtransform, J/BWTC_joined_.js:1147-1168): next(t) = LF[t] + C[T[t]] (+1 below pidx) = the stable
 // sorted position of element t; slot t holds (next(t) << 8) | T[t].  b.orig carries pidx.
-__global__ __launch_bounds__(256) void ib_pack_sentinel(const uint8_t* __restrict__ tt_all, uint32_t tt_stride, const IbBlock* __restrict__ blocks,
-                                                        const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf) {
+__global__ __launch_bounds__(256) void ib_pack_sentinel(const IbBlock* __restrict__ blocks, const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf) {
   const IbBlock b = blocks[blockIdx.y];
+  const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < b.count; j += gridDim.x * 256) {
     const uint32_t t = val[b.off + j];
-    dbuf[b.off + t] = ((j + (j < b.orig ? 1u : 0u)) << 8) | tt_all[(size_t)b.cand * tt_stride + t];
+    dbuf[b.off + t] = ((j + (j < b.orig ? 1u : 0u)) << 8) | tt[t];
   }
 }
 // splitters: slot j with j % SPL == 0, plus the start slot.  Walk until the next splitter.
@@ -949,7 +745,7 @@ static int ibwt_sentinel_slab(hipStream_t s, const uint8_t* d_T, uint32_t max_le
   uint64_t M64 = 0;
   for (uint32_t k = 0; k < nb; k++) {
     IbBlock& b = chain[k];
-    b.cand = (uint32_t)M64;                       // with a row stride of 1 the "candidate index" is the block's byte offset in d_T
+    b.tt = (uint64_t)(uintptr_t)(d_T + M64);
     b.count = lens[k]; b.orig = pidx[k]; b.off = (uint32_t)M64; b.out_off = M64; b.out_len = lens[k]; b.crc = 0;
     M64 += lens[k];
   }
@@ -972,14 +768,14 @@ static int ibwt_sentinel_slab(hipStream_t s, const uint8_t* d_T, uint32_t max_le
   sw.hist_tiles = (uint32_t)T; sw.bintot_segs = 1;
   if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
   if (rc) { cleanup(); return rc; }
-  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_T, 1u, d_blocks, d_key0, d_val0);
+  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_blocks, d_key0, d_val0);
   int cur = 0;
   int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
   rc = radix_passes_public<uint32_t>(s, sw, d_key0, d_val0, d_key1, d_val1, cur, M, 0, kbits);
   if (rc) { cleanup(); return rc; }
   uint32_t* sval = cur ? d_val1 : d_val0;
   uint32_t* d_dbuf = cur ? d_key0 : d_key1;
-  hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_T, 1u, d_blocks, sval, d_dbuf);
+  hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_blocks, sval, d_dbuf);
   hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 1);
   hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
   hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_out, 1);
@@ -1035,7 +831,8 @@ struct DecShare {
   const uint8_t* d_in = nullptr;      // addressed by absolute byte: d_in[b] is valid for up_lo <= b < up_hi
   std::vector<Cand> cands;            // sorted by bit
   std::vector<BlockOut> bos;
-  uint8_t* d_tt = nullptr;            // decoded BWT bytes, tt_stride per candidate
+  uint8_t* d_tt = nullptr;            // decoded BWT bytes of a one-batch share, tt_stride per row (several batches: packed segments)
+  std::vector<uint64_t> tt_ptr;       // per candidate: device address of its decoded bytes
   size_t cand_base = 0;               // index of cands[0] in the job's candidate list
   // chain part
   size_t c0 = 0, c1 = 0;              // chain blocks [c0, c1) were decoded here
@@ -1109,52 +906,80 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   for (auto& c : S->cands) c.pad = c.kind == 0 ? nrows++ : 0u;
   if (ncand && hipMemcpy(d_cand, S->cands.data(), sizeof(Cand) * ncand, hipMemcpyHostToDevice) != hipSuccess) { S->rc = CJS_E_HIP; return; }
   S->bos.resize(ncand);
+  S->tt_ptr.assign(ncand, 0ull);
   if (!ncand) { S->ms_a = ms_since(T0); return; }
+  // Block decode in three stages (Huffman chain per block -> (rank, offset) ops; move-to-front of all 256-op tiles in parallel;
+  // emit), over BATCHES of rows: a row of scratch is sized for a whole block of the file's largest level (~7 x tt_stride bytes),
+  // whatever the candidate turns out to hold, so a file of very many tiny member streams (or one stuffed with block magics)
+  // must not get a row per candidate at once.  One batch (the usual case: <= ~1300 level-9 rows in 8 GiB) keeps its decoded
+  // rows where they are; with several batches each batch's decoded bytes are packed into a buffer of their exact size and
+  // the scratch rows are used again.
   BlockOut* d_bo = nullptr;
-  static const bool pipe = getenv("CJS_DECODE_PIPE") != nullptr;      // the two-wave pipeline (one workgroup does Huffman + MTF of a block), kept for A/B
-  rc = S->take((void**)&S->d_tt, (size_t)(nrows ? nrows : 1) * J->tt_stride);
-  if (!rc) rc = S->take((void**)&d_bo, sizeof(BlockOut) * ncand);
-  if (rc) { S->rc = rc; return; }
   const uint32_t dsz = J->tt_stride;
-  if (pipe) {
-    hipLaunchKernelGGL(bz_decode_block_pipe, dim3(ncand), dim3(128), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, S->d_tt, d_bo);
-    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess ||
+  const uint32_t ops_stride = (dsz + 256u + 255u) & ~255u, tiles_per_row = ops_stride / MT_TILE;
+  static const uint64_t budget = getenv("CJS_DEC_ROW_BYTES") ? strtoull(getenv("CJS_DEC_ROW_BYTES"), nullptr, 10) : (8ull << 30);      // (tests shrink it)
+  const uint64_t per_row = (uint64_t)dsz + 6ull * ops_stride + 256 + 4;
+  const uint32_t nr = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(nrows ? nrows : 1u, std::max<uint64_t>(1ull, budget / per_row)));
+  const bool single = nrows <= nr;
+  uint8_t *d_ttb = nullptr, *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr; uint64_t* d_gdst = nullptr;
+  rc = S->take((void**)&d_ttb, (size_t)nr * dsz);
+  if (!rc) rc = S->take((void**)&d_bo, sizeof(BlockOut) * ncand);
+  if (!rc) rc = S->take((void**)&d_ops, (size_t)nr * ops_stride);
+  if (!rc) rc = S->take((void**)&d_opoff, 4 * (size_t)nr * ops_stride);
+  if (!rc) rc = S->take((void**)&d_l0, (size_t)nr * 256);
+  if (!rc) rc = S->take((void**)&d_pl, (size_t)nr * ops_stride);
+  if (!rc) rc = S->take((void**)&d_nops, 4 * (size_t)nr);
+  if (!rc && !single) rc = S->take((void**)&d_gdst, 8 * (size_t)nr);
+  if (rc) { S->rc = rc; return; }
+  if (single) S->d_tt = d_ttb;
+  std::vector<uint64_t> gdst(single ? 0 : nr);
+  for (uint32_t c0 = 0; c0 < ncand;) {
+    // candidates [c0, c1): at most nr block candidates (rows r0 .. r0 + rows)
+    uint32_t c1 = c0, rows = 0, r0 = 0;
+    while (c1 < ncand && (S->cands[c1].kind != 0 || rows < nr)) { if (S->cands[c1].kind == 0) { if (!rows) r0 = S->cands[c1].pad; rows++; } c1++; }
+    const uint32_t nc = c1 - c0;
+    if (rows && hipMemsetAsync(d_nops, 0, 4 * (size_t)rows, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+    hipLaunchKernelGGL(bz_huff_ops, dim3(nc), dim3(64), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_ops, d_opoff, ops_stride, d_l0, d_nops, d_bo + c0, r0);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data() + c0, d_bo + c0, sizeof(BlockOut) * nc, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
-  } else {
-    // three stages: Huffman chain per block -> (rank, offset) ops; move-to-front of all 256-op tiles in parallel; emit
-    const uint32_t ops_stride = (dsz + 256u + 255u) & ~255u, tiles_per_row = ops_stride / MT_TILE, nr = nrows ? nrows : 1;
-    uint8_t *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr;
-    rc = S->take((void**)&d_ops, (size_t)nr * ops_stride);
-    if (!rc) rc = S->take((void**)&d_opoff, 4 * (size_t)nr * ops_stride);
-    if (!rc) rc = S->take((void**)&d_l0, (size_t)nr * 256);
-    if (!rc) rc = S->take((void**)&d_pl, (size_t)nr * ops_stride);
-    if (!rc) rc = S->take((void**)&d_nops, 4 * (size_t)nr);
-    if (rc) { S->rc = rc; return; }
-    if (hipMemsetAsync(d_nops, 0, 4 * (size_t)nr, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
-    hipLaunchKernelGGL(bz_huff_ops, dim3(ncand), dim3(64), 0, s, S->d_in, S->up_hi, d_cand, ncand, dsz, d_ops, d_opoff, ops_stride, d_l0, d_nops, d_bo);
-    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data(), d_bo, sizeof(BlockOut) * ncand, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
-    uint32_t maxc = 0;
-    for (auto& b : S->bos) if (!b.err && b.count > maxc) maxc = b.count;
-    if (nrows) {
+    uint32_t maxc = 0; uint64_t packed = 0;
+    for (uint32_t c = c0; c < c1; c++) if (S->cands[c].kind == 0 && !S->bos[c].err) { maxc = std::max(maxc, S->bos[c].count); packed += ((uint64_t)S->bos[c].count + 15u) & ~15ull; }
+    if (rows) {
       const uint32_t tiles_used = std::min<uint32_t>(maxc / MT_TILE + 1u, tiles_per_row);
       // slabs of rows: grid.y <= 65535 and grid.x * grid.y * 256 threads < 2^32 (a larger launch is cut short without an error)
       const uint32_t slab = std::min<uint32_t>(65535u, std::max<uint32_t>(1u, (1u << 23) / tiles_used));
-      for (uint32_t r0 = 0; r0 < nrows; r0 += slab)
-        hipLaunchKernelGGL(bz_mtf_tiles, dim3((tiles_used + 3u) / 4u, std::min(slab, nrows - r0)), dim3(256), 0, s, d_ops, ops_stride, d_nops, d_pl, tiles_per_row, r0);
-      hipLaunchKernelGGL(bz_mtf_compose, dim3(nrows), dim3(256), 0, s, d_nops, d_l0, d_pl, tiles_per_row);
-      for (uint32_t r0 = 0; r0 < nrows; r0 += slab)
-        hipLaunchKernelGGL(bz_mtf_emit, dim3(tiles_used, std::min(slab, nrows - r0)), dim3(256), 0, s, d_ops, d_opoff, ops_stride, d_nops, d_l0, d_pl, tiles_per_row, r0, S->d_tt, dsz);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+      for (uint32_t q0 = 0; q0 < rows; q0 += slab)
+        hipLaunchKernelGGL(bz_mtf_tiles, dim3((tiles_used + 3u) / 4u, std::min(slab, rows - q0)), dim3(256), 0, s, d_ops, ops_stride, d_nops, d_pl, tiles_per_row, q0);
+      hipLaunchKernelGGL(bz_mtf_compose, dim3(rows), dim3(256), 0, s, d_nops, d_l0, d_pl, tiles_per_row);
+      for (uint32_t q0 = 0; q0 < rows; q0 += slab)
+        hipLaunchKernelGGL(bz_mtf_emit, dim3(tiles_used, std::min(slab, rows - q0)), dim3(256), 0, s, d_ops, d_opoff, ops_stride, d_nops, d_l0, d_pl, tiles_per_row, q0, d_ttb, dsz);
+      if (hipGetLastError() != hipSuccess) { S->rc = CJS_E_HIP; return; }
+      if (single) {
+        for (uint32_t c = c0; c < c1; c++) if (S->cands[c].kind == 0) S->tt_ptr[c] = (uint64_t)(uintptr_t)(d_ttb + (size_t)(S->cands[c].pad - r0) * dsz);
+      } else {
+        uint8_t* seg = nullptr;                                        // (kept until the share is released)
+        if ((rc = S->take((void**)&seg, (size_t)packed + 16)) != 0) { S->rc = rc; return; }
+        uint64_t at = 0;
+        for (uint32_t c = c0; c < c1; c++) if (S->cands[c].kind == 0) {
+          const uint32_t row = S->cands[c].pad - r0, cnt = S->bos[c].err ? 0u : S->bos[c].count;
+          gdst[row] = (uint64_t)(uintptr_t)(seg + at) | ((uint64_t)cnt << 44);       // (device addresses are below 2^44... kept apart: see bz_rows_pack)
+          S->tt_ptr[c] = (uint64_t)(uintptr_t)(seg + at);
+          at += ((uint64_t)cnt + 15u) & ~15ull;
+        }
+        if (hipMemcpyAsync(d_gdst, gdst.data(), 8 * (size_t)rows, hipMemcpyHostToDevice, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+        hipLaunchKernelGGL(bz_rows_pack, dim3(16, rows), dim3(256), 0, s, d_ttb, dsz, d_gdst);
+        if (hipGetLastError() != hipSuccess) { S->rc = CJS_E_HIP; return; }
+      }
+      if (hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
     }
-    S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops);
+    c0 = c1;
   }
+  S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops);
+  if (!single) { S->drop(d_ttb); S->drop(d_gdst); }
   if (getenv("CJS_DEBUG")) {
     uint64_t clk[8];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
-      if (!pipe) fprintf(stderr, "[cjs dec] candidate 0 (three-stage decode): Huffman chain %.1f us for %llu rank ops\n", clk[6] / 100.0, (unsigned long long)clk[7]);
-      else fprintf(stderr, "[cjs dec] candidate 0 (two-wave pipeline): %llu symbols; producer %.1f us, %llu rounds, waited for ring space %llu times; consumer %.1f us, %llu batches, found the ring empty %llu times\n",
-                   (unsigned long long)clk[7], clk[6] / 100.0, (unsigned long long)clk[5], (unsigned long long)clk[4], clk[2] / 100.0, (unsigned long long)clk[1], (unsigned long long)clk[0]);
+      fprintf(stderr, "[cjs dec] candidate 0: Huffman chain %.1f us for %llu rank ops\n", clk[6] / 100.0, (unsigned long long)clk[7]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
             (unsigned long long)S->hi, (unsigned long long)S->up_lo, (unsigned long long)S->up_hi, up_n, ncand);
@@ -1210,14 +1035,14 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     if (!rc && hipMemsetAsync(q.d_err, 0, 4 * (size_t)nb, s) != hipSuccess) rc = CJS_E_HIP;
     if (rc) break;
     uint8_t* d_wb = S->d_w + e0;
-    hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, S->d_tt, J->tt_stride, q.d_blocks, q.key0, q.val0);
+    hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, q.d_blocks, q.key0, q.val0);
     int cur = 0;
     int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
     rc = radix_passes_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, M, 0, kbits);
     if (rc) break;
     uint32_t* sval = cur ? q.val1 : q.val0;
     uint32_t* d_dbuf = cur ? q.key0 : q.key1;                      // the buffer the sort is not sitting in
-    hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, S->d_tt, J->tt_stride, q.d_blocks, sval, d_dbuf);
+    hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, q.d_blocks, sval, d_dbuf);
     hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, q.d_blocks, spl_stride, q.snext, q.ssteps, 0);
     hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, q.d_blocks, nb, spl_stride, q.snext, q.ssteps, q.srank, q.d_err);
     hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, q.d_blocks, spl_stride, q.srank, q.ssteps, d_wb, 0);
@@ -1285,11 +1110,16 @@ void dec_phase_c(DecJob* J, DecShare* S) {
 
 template <typename F>
 int for_each_share(std::vector<DecShare>& sh, DecJob* J, F fn) {
-  if (sh.size() == 1) fn(J, &sh[0]);
+  // nothing may leave a worker thread (std::terminate): an exception of a phase becomes the share's return code
+  auto guarded = [fn](DecJob* j, DecShare* s) {
+    try { fn(j, s); }
+    catch (const std::bad_alloc&) { s->rc = CJS_E_OUT_OF_MEMORY; }
+    catch (...) { s->rc = CJS_E_HIP; }
+  };
+  if (sh.size() == 1) guarded(J, &sh[0]);
   else {
-    std::vector<std::thread> th;
-    for (auto& x : sh) th.emplace_back(fn, J, &x);
-    for (auto& t : th) t.join();
+    struct JoinAll { std::vector<std::thread> th; ~JoinAll() { for (auto& t : th) if (t.joinable()) t.join(); } } workers;      // joined on every path
+    for (auto& x : sh) workers.th.emplace_back(guarded, J, &x);
   }
   for (auto& x : sh) if (x.rc) { if (x.detail[0]) set_detail("%s", x.detail); return x.rc; }
   return 0;
@@ -1346,6 +1176,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
   }
   const auto T0 = std::chrono::steady_clock::now();
   auto release_all = [&]() { for (auto& x : sh) x.release(); (void)hipSetDevice(dev0); };
+  struct ReleaseGuard { decltype(release_all)& f; ~ReleaseGuard() { f(); } } release_guard{release_all};      // also when an exception unwinds (release is idempotent)
   int rc = for_each_share(sh, &J, dec_phase_a);
   if (rc) { release_all(); return rc; }
   const double ms_a = ms_since(T0);
@@ -1370,7 +1201,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
     if (bo.err != CJS_E_OBSOLETE_INPUT && bo.orig > dbuf_size) { set_detail("initial position out of bounds"); return CJS_E_DATA_ERROR; }   // :1449-1450
     if (bo.err) return bo.err;
     if (bo.count > dbuf_size) return CJS_E_DATA_ERROR;             // decoded with the largest level's limit: this stream's is lower (:1647,1663)
-    IbBlock ib; ib.cand = S.cands[clocal[(size_t)ci]].pad; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
+    IbBlock ib; ib.tt = S.tt_ptr[clocal[(size_t)ci]]; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
     J.chain.push_back(ib); J.chain_bits.push_back(bitpos); chain_share.push_back(cshare[(size_t)ci]);
     return 0;
   };

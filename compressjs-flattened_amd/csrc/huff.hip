@@ -787,9 +787,8 @@ int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A
   if (nb == 0) return 0;
   static const bool dbg = getenv("CJS_DEBUG") != nullptr;
   // one workgroup per block (huff_block) keeps nb CUs busy; with fewer blocks than CUs the chain of kernels spreads the
-  // data-parallel phases over the whole chip (CJS_HUFF_SPLIT=0 / 1 forces one form)
-  static const int env_split = getenv("CJS_HUFF_SPLIT") ? atoi(getenv("CJS_HUFF_SPLIT")) : -1;
-  const bool split = env_split >= 0 ? env_split != 0 : (nb >= 8 && nb <= 512 && (size_t)nb * w.max_stride >= ((size_t)8 << 20));
+  // data-parallel phases over the whole chip
+  const bool split = nb >= 8 && nb <= 512 && (size_t)nb * w.max_stride >= ((size_t)8 << 20);
   if (split) {
     const uint32_t max_sel = (uint32_t)(((size_t)w.max_stride + 1 + GSZ - 1) / GSZ);
     const uint32_t ga = (max_sel + HS_STEPS * AS_GROUPS - 1) / (HS_STEPS * AS_GROUPS), gc = (w.max_stride + 1 + HS_CNT - 1) / HS_CNT;

@@ -38,6 +38,7 @@ struct cjs_ctx {
   EventTimer timer;
   // phase state of a multi-GPU job (cjs_bzip2_shard_tiles -> _blocks -> _pack)
   uint32_t sh_nb = 0, sh_first = 0, sh_cnt = 0, sh_state = 0;
+  bool stage_times = true;         // cjs_ctx_set_stage_times
 };
 
 extern "C" int cjs_ctx_create(cjs_ctx** out, int device, size_t max_input, int level) {
@@ -78,7 +79,7 @@ extern "C" int cjs_ctx_create_sharded(cjs_ctx** out, int device, size_t max_inpu
     if (!c->d_pidx) rc = CJS_E_OUT_OF_MEMORY;
   }
   if (!rc && hipStreamCreate(&c->stream) != hipSuccess) rc = CJS_E_HIP;
-  if (!rc && !getenv("CJS_NO_SIDE_STREAM") && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipHostMalloc((void**)&c->h_scalars, 256) != hipSuccess) rc = CJS_E_HIP;
@@ -88,6 +89,8 @@ extern "C" int cjs_ctx_create_sharded(cjs_ctx** out, int device, size_t max_inpu
   return 0;
   CJS_GUARD_END(CJS_E_OUT_OF_MEMORY, CJS_E_HIP)
 }
+
+extern "C" void cjs_ctx_set_stage_times(cjs_ctx* c, int on) { if (c) c->stage_times = on != 0; }
 
 extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
   if (!c) return;
@@ -195,7 +198,7 @@ static int compress_core_impl(cjs_ctx* c, const uint8_t* d_in, size_t n, int lev
   c->sh_state = 0;
   EvPair evp;
   hipEvent_t &ev0 = evp.a, &ev1 = evp.b;
-  const bool stage_times = st && !(st->flags & CJS_STATS_NO_STAGE_TIMES);
+  const bool stage_times = st && c->stage_times;
   if (st) { memset(st, 0, sizeof *st); CJS_HIP_TRY(hipEventCreate(&ev0)); CJS_HIP_TRY(hipEventCreate(&ev1)); (void)hipEventRecord(ev0, s); }
   uint32_t nb = 0, last_len = 0;
   if (stage_times) c->timer.start();
@@ -272,7 +275,7 @@ static int shard_blocks_impl(cjs_ctx* c, const uint8_t* d_in, size_t n, int leve
   hipStream_t s = c->stream;
   c->sh_state = 0;
   EvPair evp;
-  const bool stage_times = st && !(st->flags & CJS_STATS_NO_STAGE_TIMES);
+  const bool stage_times = st && c->stage_times;
   if (st) { memset(st, 0, sizeof *st); CJS_HIP_TRY(hipEventCreate(&evp.a)); CJS_HIP_TRY(hipEventCreate(&evp.b)); (void)hipEventRecord(evp.a, s); }
   if (stage_times) c->timer.start();
   uint32_t nb = 0, last_len = 0;
@@ -637,6 +640,7 @@ extern "C" int cjs_bzip2_compress(const uint8_t* in, size_t n, int level, uint8_
   const auto t2 = now();
   size_t len = 0;
   cjs_stats* st = (opts && opts->struct_size >= sizeof(cjs_opts)) ? opts->stats : nullptr;
+  c->stage_times = !(opts && opts->struct_size >= sizeof(cjs_opts) && (opts->flags & CJS_FLAG_NO_STAGE_TIMES));
   if (!rc) rc = cjs_bzip2_compress_device(c, hc.d_in, n, level, hc.d_out, out_cap, &len, st);
   const auto t3 = now();
   uint8_t* host = nullptr;

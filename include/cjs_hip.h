@@ -45,11 +45,8 @@ typedef struct cjs_stats {
   uint64_t blocks;
   uint64_t bytes_in, bytes_out;
   uint32_t bwt_rounds;
-  uint32_t flags;         /* IN: CJS_STATS_* (read before the struct is cleared and filled) */
-} cjs_stats;
-/* no stream synchronisation between the stages: ms_rle1 / ms_bwt / ms_mtf / ms_huff / ms_pack stay 0, the rest is filled
- * (whole-call events, dominant-kernel events, counts).  What bench.py passes inside its timed loop. */
-#define CJS_STATS_NO_STAGE_TIMES 1u
+  uint32_t reserved;      /* written as 0 */
+} cjs_stats;               /* OUT only: cleared and filled by the call, never read */
 /* cjs_bwtc_compress fills the same struct with wall-clock times of its two halves: ms_total = whole call, ms_bwt =
  * longest GPU batch (workspace + H2D + BWT + MTF + model), ms_mtf = time until the first step list reached the host,
  * ms_pack = serial range coder over the step lists (host), ms_rle1 = time the coder spent waiting for the GPU. */
@@ -64,6 +61,10 @@ typedef struct cjs_opts {
 /* cjs_bwtc_compress: the input came from a stream without a known size, so the header carries varint(0) instead of
  * varint(size+1) (Util.compressFileHelper, J/BWTC_joined_.js:529-543) */
 #define CJS_FLAG_SIZE_UNKNOWN 1u
+/* cjs_bzip2_compress with opts->stats: no stream synchronisation between the stages -- ms_rle1 / ms_bwt / ms_mtf / ms_huff /
+ * ms_pack stay 0, the rest is filled (whole-call events, dominant-kernel events, counts).  Device-resident entry points:
+ * cjs_ctx_set_stage_times(ctx, 0). */
+#define CJS_FLAG_NO_STAGE_TIMES 2u
 
 /* ---- host-buffer entry points (what the JS fronts bind).
  * cjs_bzip2_compress   replaces Bzip2.compressFile    J/Bzip2_joined_.js:2199-2249
@@ -107,6 +108,10 @@ int cjs_ctx_create(cjs_ctx **ctx, int device, size_t max_input, int level);
  * max_range_blocks blocks per call: for cjs_bzip2_compress_device_range on a replicated stream */
 int cjs_ctx_create_sharded(cjs_ctx **ctx, int device, size_t max_input, long max_range_blocks, int level);
 void cjs_ctx_destroy(cjs_ctx *ctx);
+/* Calls on this context that are given a cjs_stats: on != 0 (default) synchronise the stream between the stages and fill the
+ * per-stage times; on == 0 only record events (whole call, every full-size launch of the dominant kernel) -- what bench.py
+ * sets for its timed loop. */
+void cjs_ctx_set_stage_times(cjs_ctx *ctx, int on);
 /* d_in/d_out are device pointers; d_out has out_cap bytes; *out_n receives the stream length.
  * Synchronous on return (the context stream has drained). */
 int cjs_bzip2_compress_device(cjs_ctx *ctx, const uint8_t *d_in, size_t n, int level,

@@ -79,7 +79,7 @@ def test_device_output_too_small_is_refused_without_writing(oracle):
     back = d_out.cpu().numpy()
     assert (back == 0xAB).all()
     st = pkg.Stats()
-    st.flags = pkg.Stats.NO_STAGE_TIMES
+    ctx.set_stage_times(False)         # events only: no per-stage synchronisation (what bench.py's timed loop uses)
     n = ctx.compress(d_in.data_ptr(), data.size, d_out.data_ptr(), (want.size + 8 + 3) & ~3, st)
     assert n == want.size and np.array_equal(d_out[:n].cpu().numpy(), want)
     assert st.ms_total > 0 and st.ms_bwt == 0 and st.bwt_dominant_launches > 0 and st.blocks == 4
@@ -333,21 +333,13 @@ def _run_variant(env, n, seed, level):
     return int(rc_s), sha
 
 
-@pytest.mark.parametrize("env", [{"CJS_R1_PACKED": "0"}, {"CJS_R1_PACKED": "1"}, {"CJS_APPLY_HALVES": "0"}, {"CJS_APPLY_HALVES": "2"},
-                                 {"CJS_TILE_SORT": "radix"}, {"CJS_TILE_SORT": "count"}, {"CJS_R1_TWO_PHASE": "1"}, {"CJS_R1_TWO_PHASE": "0"}, {"CJS_NO_TILE_SORT": "1"}, {"CJS_NO_SEGMENTED_SORT": "1"},
-                                 {"CJS_APPLY_HALVES": "3"}, {"CJS_APPLY_HALVES": "2"},
-                                 {"CJS_FUSE_GATHER": "0"}, {"CJS_FUSE_GATHER": "0", "CJS_TILE_SORT": "radix"}, {"CJS_FUSE_GATHER": "1", "CJS_TILE_SORT": "count"},
-                                 {"CJS_R1_PACKED": "1", "CJS_APPLY_HALVES": "2", "CJS_TILE_SORT": "radix"},
-                                 {"CJS_DIRECT_EMIT": "0"}, {"CJS_R1_DIG": "0"}, {"CJS_R1_TEXT_HIST": "0"}, {"CJS_HB_HR": "2"}, {"CJS_HB_HR": "8"}, {"CJS_BIG_GROUP_TEST": "0"},
-                                 {"CJS_HUFF_SPLIT": "1"}, {"CJS_HUFF_SPLIT": "0"}],
-                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
-def test_suffix_sort_variants_are_bit_exact(oracle, env):
-    # every A/B toggle of the suffix sorter (round-1 record format, two-sweep rank scatter, tile sorter flavour, fallbacks, direct
-    # emit, digit bytes, large-group test) and the two forms of the Huffman refinement (one kernel per block / chain of kernels)
-    # must give the same stream: 2.5 MB at level 9 (three blocks) and 1.2 MB at level 1 (13 blocks: the two-sweep path needs >= 8)
-    cases = [(2500000, 4, 9), (1200000, 6, 1)]
-    if "CJS_APPLY_HALVES" in env or "CJS_HUFF_SPLIT" in env or "CJS_BIG_GROUP_TEST" in env:
-        cases.append((7400000, 8, 9))        # nine level-9 blocks: the two-sweep gather / scatter of rounds >= 2 runs for several rounds
+@pytest.mark.parametrize("env", [{}, {"CJS_NO_SEGMENTED_SORT": "1"}], ids=["default", "unsegmented-fallback"])
+def test_suffix_sort_paths_are_bit_exact(oracle, env):
+    # the paths the sorter picks by itself, each in a fresh process: packed two-phase round 1 with the two-sweep regroup (>= 8
+    # blocks) and without (3 blocks), both tile sorters (radix while groups are large, counting / bitonic later), the Huffman
+    # refinement as one kernel per block (< 8 blocks or < 8 MB) and as a chain of kernels (10 level-9 blocks); and the fallback
+    # for inputs of more segments than the workspace was carved for (keys materialised, one plain radix sort; forced here)
+    cases = [(2500000, 4, 9), (1200000, 6, 1), (9100000, 8, 9)]
     for n, seed, level in cases:
         rc, want = oracle.bzip2_compress(recipes.textgen(n, seed), level)
         rc_v, sha = _run_variant(env, n, seed, level)
@@ -432,6 +424,40 @@ def test_multistream_with_more_than_65535_blocks(hip, oracle):
     assert rc == 0, hip.L.cjs_strerror(rc)
     assert out.size == 3 * reps and out.tobytes() == b"xyz" * reps
     hip.L.cjs_trim()
+
+
+def test_many_tiny_members_under_level9_headers(hip, oracle):
+    # 70,000 member streams that announce level 9: a scratch row is sized for a 900 kB block whatever the member holds, so the
+    # block decode runs in row batches under a byte budget (a row per candidate at once would be ~440 GB here; the reference
+    # decodes the file trivially).  With several batches each batch's decoded bytes are packed and the rows reused.
+    one = oracle.bzip2_compress(b"x", 9)[1]
+    two = oracle.bzip2_compress(b"yz", 9)[1]
+    reps = 35000
+    cat = np.tile(np.concatenate([one, two]), reps)
+    rc, out = hip.bzip2_decompress(cat, 1)
+    assert rc == 0, hip.L.cjs_strerror(rc)
+    assert out.size == 3 * reps and out.tobytes() == b"xyz" * reps
+    rc, tab = hip.bzip2_table(cat, 1, cap=2 * reps + 8)
+    assert rc == 0 and len(tab) == 2 * reps
+    hip.L.cjs_trim()
+
+
+def test_decode_row_batches_match_the_single_batch(oracle):
+    # the same file decoded with room for all rows at once and with room for two rows per batch (CJS_DEC_ROW_BYTES): text blocks
+    # of three levels, a damaged block (error reported as before) and a table listing
+    code = ("import sys; sys.path.insert(0, 'tests'); import torch, support, recipes, numpy as np; h = support.HipLib(); o = support.Oracle(); "
+            "parts = [recipes.textgen(2600000, 3), recipes.textgen(950000, 4), recipes.textgen(400000, 5)]; "
+            "cat = np.concatenate([o.bzip2_compress(d, l)[1] for d, l in zip(parts, (9, 3, 1))]); "
+            "rc, out = h.bzip2_decompress(cat, 1); rc2, tab = h.bzip2_table(cat, 1); "
+            "bad = cat.copy(); bad[bad.size // 3] ^= 0x10; rc3, _ = h.bzip2_decompress(bad, 1); "
+            "print(rc, support.sha256(out), support.sha256(np.concatenate(parts)), rc2, len(tab), rc3, h.last_error_detail().split(' (')[0])")
+    res = []
+    for env in ({}, {"CJS_DEC_ROW_BYTES": str(14 * 900000)}):
+        o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), cwd=ROOT, timeout=300)
+        assert o.returncode == 0, o.stderr[-1500:]
+        res.append(o.stdout.split())
+    assert res[0] == res[1], res
+    assert res[0][0] == "0" and res[0][1] == res[0][2] and res[0][3] == "0" and res[0][5] in ("-5", "-2")
 
 
 def test_bwtc_decompress_negative_inputs(hip, oracle):
