@@ -117,6 +117,16 @@ struct LaunchTimes {   // event pairs around the dominant kernel; resolved after
     reset();
   }
   void reset() { for (int i = 0; i < made; i++) (void)hipEventDestroy(ev[i]); n = made = 0; }
+  ~LaunchTimes() { reset(); }
+  // hands the recorded launches to `to` (appended; this object is left empty, still enabled)
+  void move_into(LaunchTimes& to) {
+    for (int i = 0; i < n && to.n < MAXP; i++) {
+      if (to.made > 2 * to.n) { for (int j = 2 * to.n; j < to.made; j++) (void)hipEventDestroy(to.ev[j]); to.made = 2 * to.n; }
+      to.ev[2 * to.n] = ev[2 * i]; to.ev[2 * to.n + 1] = ev[2 * i + 1]; to.elems[to.n] = elems[i]; to.n++; to.made = 2 * to.n;
+    }
+    for (int i = 2 * n; i < made; i++) (void)hipEventDestroy(ev[i]);
+    n = made = 0;
+  }
 };
 
 struct BwtWork {

@@ -472,11 +472,12 @@ __global__ __launch_bounds__(256) void bz_mtf_emit(const uint8_t* __restrict__ q
   }
 }
 
-// decoded rows of a batch -> their packed places (phase A with several batches): desc[row] = destination address | count << 44
-__global__ __launch_bounds__(256) void bz_rows_pack(const uint8_t* __restrict__ rows, uint32_t stride, const uint64_t* __restrict__ desc) {
-  const uint64_t d = desc[blockIdx.y];
-  uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(d & ((1ull << 44) - 1ull));
-  const uint32_t cnt = (uint32_t)(d >> 44);
+// decoded rows of a batch -> their packed places (phase A with several batches)
+struct RowDst { uint64_t dst; uint64_t count; };      // device address of the row's packed place, bytes to copy
+__global__ __launch_bounds__(256) void bz_rows_pack(const uint8_t* __restrict__ rows, uint32_t stride, const RowDst* __restrict__ desc) {
+  const RowDst d = desc[blockIdx.y];
+  uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(d.dst);
+  const uint32_t cnt = (uint32_t)d.count;
   const uint8_t* __restrict__ src = rows + (size_t)blockIdx.y * stride;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) dst[i] = src[i];
 }
@@ -919,9 +920,9 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   const uint32_t ops_stride = (dsz + 256u + 255u) & ~255u, tiles_per_row = ops_stride / MT_TILE;
   static const uint64_t budget = getenv("CJS_DEC_ROW_BYTES") ? strtoull(getenv("CJS_DEC_ROW_BYTES"), nullptr, 10) : (8ull << 30);      // (tests shrink it)
   const uint64_t per_row = (uint64_t)dsz + 6ull * ops_stride + 256 + 4;
-  const uint32_t nr = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(nrows ? nrows : 1u, std::max<uint64_t>(1ull, budget / per_row)));
+  const uint32_t nr = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nrows ? nrows : 1u, 65535u), std::max<uint64_t>(1ull, budget / per_row)));      // (<= grid.y)
   const bool single = nrows <= nr;
-  uint8_t *d_ttb = nullptr, *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr; uint64_t* d_gdst = nullptr;
+  uint8_t *d_ttb = nullptr, *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr; RowDst* d_gdst = nullptr;
   rc = S->take((void**)&d_ttb, (size_t)nr * dsz);
   if (!rc) rc = S->take((void**)&d_bo, sizeof(BlockOut) * ncand);
   if (!rc) rc = S->take((void**)&d_ops, (size_t)nr * ops_stride);
@@ -929,10 +930,10 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (!rc) rc = S->take((void**)&d_l0, (size_t)nr * 256);
   if (!rc) rc = S->take((void**)&d_pl, (size_t)nr * ops_stride);
   if (!rc) rc = S->take((void**)&d_nops, 4 * (size_t)nr);
-  if (!rc && !single) rc = S->take((void**)&d_gdst, 8 * (size_t)nr);
+  if (!rc && !single) rc = S->take((void**)&d_gdst, sizeof(RowDst) * (size_t)nr);
   if (rc) { S->rc = rc; return; }
   if (single) S->d_tt = d_ttb;
-  std::vector<uint64_t> gdst(single ? 0 : nr);
+  std::vector<RowDst> gdst(single ? 0 : nr);
   for (uint32_t c0 = 0; c0 < ncand;) {
     // candidates [c0, c1): at most nr block candidates (rows r0 .. r0 + rows)
     uint32_t c1 = c0, rows = 0, r0 = 0;
@@ -962,11 +963,11 @@ void dec_phase_a(DecJob* J, DecShare* S) {
         uint64_t at = 0;
         for (uint32_t c = c0; c < c1; c++) if (S->cands[c].kind == 0) {
           const uint32_t row = S->cands[c].pad - r0, cnt = S->bos[c].err ? 0u : S->bos[c].count;
-          gdst[row] = (uint64_t)(uintptr_t)(seg + at) | ((uint64_t)cnt << 44);       // (device addresses are below 2^44... kept apart: see bz_rows_pack)
+          gdst[row] = RowDst{(uint64_t)(uintptr_t)(seg + at), cnt};
           S->tt_ptr[c] = (uint64_t)(uintptr_t)(seg + at);
           at += ((uint64_t)cnt + 15u) & ~15ull;
         }
-        if (hipMemcpyAsync(d_gdst, gdst.data(), 8 * (size_t)rows, hipMemcpyHostToDevice, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
+        if (hipMemcpyAsync(d_gdst, gdst.data(), sizeof(RowDst) * (size_t)rows, hipMemcpyHostToDevice, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
         hipLaunchKernelGGL(bz_rows_pack, dim3(16, rows), dim3(256), 0, s, d_ttb, dsz, d_gdst);
         if (hipGetLastError() != hipSuccess) { S->rc = CJS_E_HIP; return; }
       }

@@ -28,6 +28,16 @@ struct HuffWork {
   static size_t sel_stride_for(uint32_t stride) { return (((size_t)stride + 1 + 49) / 50 + 63) & ~(size_t)63; }
   static size_t bytes_needed(size_t max_blocks, uint32_t stride);
   int carve(Arena& a, size_t max_blocks, uint32_t stride);
+  // the table-construction buffers seen from block `first` on (`count` blocks); bitoff / scalars belong to the packing of a whole call
+  HuffWork view(size_t first, size_t count) const {
+    HuffWork v = *this;
+    v.max_blocks = count;
+    v.b.sel += first * b.sel_stride; v.b.selj += first * b.sel_stride; v.b.bcost += first * b.sel_stride;
+    v.b.lens += first * 6 * 258; v.b.codes += first * 6 * 258;
+    v.b.ngroups += first; v.b.bitlen += first; v.b.databits += first; v.b.tileoff += first * b.tile_stride;
+    v.b.wl += first * 6 * 264; v.b.wfreq += first * 6 * 260;
+    return v;
+  }
 };
 
 int huff_tables_run(hipStream_t s, HuffWork& w, uint32_t nb, const uint16_t* d_A, size_t a_stride, const uint32_t* d_npos,

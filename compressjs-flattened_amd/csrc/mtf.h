@@ -28,6 +28,16 @@ struct MtfWork {
   static size_t a_stride_for(uint32_t stride) { return ((size_t)stride + 2 + 7) & ~(size_t)7; }
   static size_t bytes_needed(size_t max_blocks, uint32_t stride);
   int carve(Arena& a, size_t max_blocks, uint32_t stride);
+  // the same workspace seen from block `first` on (`count` blocks): a piece of a call that is worked on by itself
+  MtfWork view(size_t first, size_t count) const {
+    MtfWork v = *this;
+    v.max_blocks = count;
+    v.b.hpos += first * b.hstride; v.b.hsym += first * b.hstride; v.b.hrank += first * b.hstride;
+    v.b.lists += first * b.list_stride; v.b.A += first * b.a_stride; v.b.freq += first * 258; v.b.alist += first * 256;
+    v.b.asz += first; v.b.nheads += first; v.b.npos += first;
+    v.b.segkeys += first * b.seg_stride * 256;
+    return v;
+  }
 };
 
 // d_U: BWT bytes, block k at k*stride with length d_blen[k]

@@ -25,7 +25,8 @@ struct cjs_ctx {
   size_t max_input = 0, max_blocks = 0, range_blocks = 0;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;            // block CRCs run here, beside the suffix sort
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t tail = nullptr;            // MTF / Huffman tables of a finished piece run here, beside the suffix sort of the next piece
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_piece[8] = {}, ev_tail = nullptr;
   Arena arena;
   Rle1Work rle;
   BwtWork bwt;
@@ -80,6 +81,9 @@ extern "C" int cjs_ctx_create_sharded(cjs_ctx** out, int device, size_t max_inpu
   }
   if (!rc && hipStreamCreate(&c->stream) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking) != hipSuccess) rc = CJS_E_HIP;
+  for (int i = 0; i < 8 && !rc; i++) if (hipEventCreateWithFlags(&c->ev_piece[i], hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
+  if (!rc && hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
   if (!rc && hipHostMalloc((void**)&c->h_scalars, 256) != hipSuccess) rc = CJS_E_HIP;
@@ -96,6 +100,9 @@ extern "C" void cjs_ctx_destroy(cjs_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   c->timer.destroy();
+  for (int i = 0; i < 8; i++) if (c->ev_piece[i]) (void)hipEventDestroy(c->ev_piece[i]);
+  if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+  if (c->tail) (void)hipStreamDestroy(c->tail);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -176,7 +183,13 @@ static int blocks_through_tables(cjs_ctx* c, const uint8_t* d_in, size_t n, uint
   // all per-block buffers below are indexed relative to `f`; only rle.block_len / block_crc are absolute
   CJS_TRY(rle1_finish(s, c->rle, d_in, n, f, cnt, c->d_blocks, c->side, c->ev_fork, c->ev_join));
   if (stage_times) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_rle1 = c->timer.stop(); }
-  if (cnt) {
+  // The suffix sort keeps the memory system busy and the SIMDs idle; MTF / RLE2 and the Huffman tables are latency-bound chains
+  // of small kernels that leave the memory system idle.  So the blocks go in `pieces` runs: while the sort of piece i + 1 runs on
+  // the work stream, MTF and the tables of piece i run beside it on the tail stream (per-stage times: one piece, one stream).
+  static const uint32_t env_pieces = getenv("CJS_PIECES") ? (uint32_t)atoi(getenv("CJS_PIECES")) : 2u;
+  uint32_t pieces = stage_times || !c->tail ? 1u : std::min<uint32_t>(std::min<uint32_t>(env_pieces, 8u), cnt / 16u);     // (a piece of < 16 blocks does not fill the chip)
+  if (pieces < 1) pieces = 1;
+  if (cnt && pieces == 1) {
     if (stage_times) c->timer.start();
     CJS_TRY(bwt_run(s, c->bwt, c->d_blocks, cnt, c->cap, n_last, true, c->d_U, c->d_pidx, st, stage_times));
     if (stage_times) { st->ms_bwt = c->timer.stop(); c->timer.start(); }
@@ -184,6 +197,24 @@ static int blocks_through_tables(cjs_ctx* c, const uint8_t* d_in, size_t n, uint
     if (stage_times) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_mtf = c->timer.stop(); c->timer.start(); }
     CJS_TRY(huff_tables_run(s, c->huff, cnt, c->mtf.b.A, c->mtf.b.a_stride, c->mtf.b.npos, c->mtf.b.asz, c->mtf.b.freq, c->mtf.b.alist));
     if (stage_times) { CJS_HIP_TRY(hipStreamSynchronize(s)); st->ms_huff = c->timer.stop(); }
+  } else if (cnt) {
+    const uint32_t per = (cnt + pieces - 1) / pieces;
+    LaunchTimes keep;                                      // the dominant-kernel events of all pieces are resolved together
+    for (uint32_t i = 0, k0 = 0; k0 < cnt; i++, k0 += per) {
+      const uint32_t kc = std::min(per, cnt - k0);
+      const bool has_last = k0 + kc == cnt;
+      CJS_TRY(bwt_run(s, c->bwt, c->d_blocks + (size_t)k0 * c->cap, kc, c->cap, has_last ? n_last : c->cap, true, c->d_U + (size_t)k0 * c->cap, c->d_pidx + k0, st, false));
+      if (st) { c->bwt.lt.move_into(keep); }
+      CJS_HIP_TRY(hipEventRecord(c->ev_piece[i], s));
+      CJS_HIP_TRY(hipStreamWaitEvent(c->tail, c->ev_piece[i], 0));
+      MtfWork mv = c->mtf.view(k0, kc);
+      HuffWork hv = c->huff.view(k0, kc);
+      CJS_TRY(mtf_run(c->tail, mv, c->d_U + (size_t)k0 * c->cap, kc, c->rle.block_len + f + k0));
+      CJS_TRY(huff_tables_run(c->tail, hv, kc, mv.b.A, mv.b.a_stride, mv.b.npos, mv.b.asz, mv.b.freq, mv.b.alist));
+    }
+    if (st) keep.move_into(c->bwt.lt);
+    CJS_HIP_TRY(hipEventRecord(c->ev_tail, c->tail));
+    CJS_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
   }
   return 0;
 }

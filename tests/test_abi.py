@@ -113,3 +113,22 @@ def test_node_addon_loads_and_mirrors_the_reference_api():
     assert r["level"] == "Invalid block size multiplier"
     if r["devices"] == 0:
         assert r["code"] == -30, r
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_cli_checks_and_messages_of_the_reference():
+    # the argument checks of NPM/bin/compressjs:31-58 with their texts; without a GPU a real call fails loudly (no fallback)
+    cli = os.path.join(PKG, "js", "cli.js")
+
+    def run(*args, data=b""):
+        return subprocess.run(["node", cli] + list(args), input=data, capture_output=True, timeout=60)
+    assert b"Can't specify both -9 and -1" in run("-z", "-9", "-1", "-t", "bzip2").stderr
+    assert b"Compression level has no effect when decompressing." in run("-d", "-3", "-t", "bwtc").stderr
+    assert b"Must specify either -d or -z." in run("-d", "-z", "-t", "bzip2").stderr
+    assert b"--block can only be used with decompression" in run("-z", "-b", "32", "-t", "bzip2").stderr
+    assert b"Unknown compressor: lzp3" in run("-z", "-t", "lzp3").stderr
+    assert run("-z", "-9", "-1", "-t", "bzip2").returncode == 1
+    import torch
+    if not torch.cuda.is_available():
+        out = run("-z", "-t", "bzip2", data=b"abc")
+        assert out.returncode == 1 and b"no HIP device" in out.stderr

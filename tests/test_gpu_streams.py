@@ -518,3 +518,38 @@ def test_bzip2_round_trip_above_4gib(hip):
     rc, back = hip.bzip2_decompress(comp)
     assert rc == 0, (hip.L.cjs_strerror(rc), hip.last_error_detail())
     assert back.size == n and support.sha256(back) == want
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_cli_round_trips_a_reference_fixture(oracle):
+    # js/cli.js over the two fronts (NPM/bin/compressjs:7-25,60-120,175): file -> file and stdin -> stdout, both algorithms;
+    # a file input knows its size, a pipe does not (BWTC then writes varint(0), like the reference for a stream without .size)
+    cli = os.path.join(ROOT, "compressjs-flattened_amd", "js", "cli.js")
+    src = os.path.join(ROOT, "tests", "golden", "data", "sample1.ref")
+    data = np.fromfile(src, dtype=np.uint8)
+    with tempfile.TemporaryDirectory() as tmp:
+        for t, level in (("bzip2", 9), ("bwtc", 5), ("bzip", 1)):
+            comp, back = os.path.join(tmp, "c." + t), os.path.join(tmp, "b." + t)
+            r = subprocess.run(["node", cli, "-z", "-t", t, "-%d" % level, src, comp], capture_output=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            got = np.fromfile(comp, dtype=np.uint8)
+            rc, want = (oracle.bwtc_compress if t == "bwtc" else oracle.bzip2_compress)(data, level)
+            assert rc == 0 and np.array_equal(got, want), t
+            r = subprocess.run(["node", cli, "-d", "-t", t, comp, back], capture_output=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            assert np.array_equal(np.fromfile(back, dtype=np.uint8), data), t
+        # pipes; default level 7
+        r = subprocess.run(["node", cli, "-z", "-t", "bzip2"], input=data.tobytes(), capture_output=True, timeout=120)
+        assert r.returncode == 0 and np.array_equal(np.frombuffer(r.stdout, dtype=np.uint8), oracle.bzip2_compress(data, 7)[1])
+        r2 = subprocess.run(["node", cli, "-d", "-t", "bzip2"], input=r.stdout, capture_output=True, timeout=120)
+        assert r2.returncode == 0 and r2.stdout == data.tobytes()
+        w = subprocess.run(["node", cli, "-z", "-t", "bwtc", "-9"], input=data.tobytes(), capture_output=True, timeout=120)
+        assert w.returncode == 0 and w.stdout[:5] == b"bwtc\x80"                      # size unknown: varint(0)
+        w2 = subprocess.run(["node", cli, "-d", "-t", "bwtc"], input=w.stdout, capture_output=True, timeout=120)
+        assert w2.returncode == 0 and w2.stdout == data.tobytes()
+        # one block by bit position (Bzip2.decompressBlock): the first block starts at bit 32
+        comp = os.path.join(tmp, "c.bzip2")
+        b = subprocess.run(["node", cli, "-d", "-t", "bzip2", "-b", "32", comp], capture_output=True, timeout=120)
+        assert b.returncode == 0 and b.stdout == data.tobytes()                        # sample1 at level 9 is one block
+        bad = subprocess.run(["node", cli, "-d", "-t", "bzip2"], input=b"not a bzip2 file at all", capture_output=True, timeout=120)
+        assert bad.returncode == 1 and b"Not bzip data" in bad.stderr
