@@ -106,10 +106,8 @@ struct DecShared {
   uint16_t fast[6][1024];          // (sym << 5) | len, 0 = not decodable within 10 bits
   uint8_t minlen[8], maxlen[8];
   uint8_t length[6][260];
-  uint8_t selectors[32768];
-  uint8_t mtf[256];
+  uint8_t mtf[8];
   uint8_t sym_to_byte[256];
-  uint32_t byte_count[256];
 };
 
 // big-endian 32-bit word `dw` of the stream, zeros past the end (the reference's reader yields zero bits there, :149)
@@ -141,7 +139,7 @@ struct BitWin {
 // Block header, selector list, code lengths (lane 0, serial) and the decode tables (whole wave).  Executed by ONE wave;
 // the results are wave-uniform scalars.  Returns 0 or a CJS_E_* code.
 __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint32_t& crc, uint32_t& orig, uint32_t& sym_total,
-                            uint32_t& group_count, uint32_t& n_sel) {
+                            uint32_t& group_count, uint32_t& n_sel, uint8_t* __restrict__ selectors /* global, room for 32768 */) {
   int err = 0;
   sym_total = 0; group_count = 0; n_sel = 0; orig = 0;
   const int lane = lane_id();
@@ -161,8 +159,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     n_sel = r.get(15);
     if (!err && n_sel == 0) err = CJS_E_DATA_ERROR;
     if (!err) {
-      for (int i = 0; i < 256; i++) S.mtf[i] = 0;
-      for (uint32_t i = 0; i < group_count; i++) S.mtf[i] = (uint8_t)i;
+      for (uint32_t i = 0; i < 8; i++) S.mtf[i] = (uint8_t)i;
       for (uint32_t i = 0; i < n_sel && !err; i++) {
         uint32_t j = 0;
         while (r.get(1)) { if (j >= group_count) { err = CJS_E_DATA_ERROR; break; } j++; }
@@ -170,7 +167,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
         const uint8_t v = S.mtf[j];
         for (uint32_t k = j; k > 0; k--) S.mtf[k] = S.mtf[k - 1];
         S.mtf[0] = v;
-        S.selectors[i] = v;
+        selectors[i] = v;
       }
     }
     if (!err) {                                              // code lengths (:1500-1520)
@@ -224,7 +221,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
         S.fast[g][x] = e;
       }
     }
-    for (int i = lane; i < 256; i += 64) { S.byte_count[i] = 0; S.mtf[i] = (uint8_t)i; }
   }
   __builtin_amdgcn_wave_barrier();
   crc = __builtin_amdgcn_readfirstlane(crc);
@@ -235,159 +231,302 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
 
 __device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
 #define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
-// ---------------------------------------------------------------- 2b. block decode in three stages
-// The Huffman chain of a block is serial (the table changes every 50 symbols, so there is no self-synchronisation to
-// exploit), but nothing BEHIND it has to be:
-//   bz_huff_ops     one wave per candidate follows the code chain (64 table lookups per round + readlane hops) and keeps
-//                   only scalar bookkeeping per symbol: RUNA/RUNB digits fold into the running output offset, every
-//                   rank symbol leaves as (rank, output offset); 64 of them per coalesced store.  No move-to-front, no
-//                   output bytes, no second wave to wait for.
+// ---------------------------------------------------------------- 2b. block decode in stages
+// The Huffman chain of a block looks serial -- the table changes every 50 symbols, so there is no self-synchronisation to exploit
+// -- but the only thing one group of 50 symbols hands to the next is WHERE IT ENDS.  So:
+//   bz_chain        one workgroup per candidate: header, selector list and code tables (wave 0), then group by group the bit
+//                   position 50 codes further on.  For every bit position i of the group's span (<= 50 x the table's longest
+//                   code) thread i looks up the length of the code that WOULD start there: next[i] = i + len.  Five rounds of
+//                   pointer doubling in LDS (next^2, next^4 .. next^32) and three hops (32 + 16 + 2) give next^50(0).  About ten
+//                   LDS round trips per 50 symbols instead of 50 x (lookup + hop) by one lone wave.
+//   bz_group_syms   one lane per group, all groups of all candidates at once: the 50 symbols from the group's start; the first
+//                   end-of-block symbol and the first undecodable code of the block by 64-bit atomic minima.
+//   bz_sym_ops      one workgroup per candidate over the symbols in front of the end-of-block: RUNA/RUNB digits -> byte counts,
+//                   running output offset, every rank symbol leaves as (rank, output offset).  No move-to-front, no output bytes.
 //   bz_mtf_tiles    the move-to-front of 256 consecutive rank ops of a block, started from the identity list, by one wave
 //                   (list as bytes across the lanes, shift by wave_shr DPP): op j becomes q_j = the slot of the TILE-START
 //                   list it reads, and the tile leaves its permutation P_t.   All tiles of all blocks in parallel.
 //   bz_mtf_compose  one workgroup per block chains the tiles: start list L_(t+1)[p] = L_t[P_t[p]] (an LDS gather per tile).
 //   bz_mtf_emit     one thread per op: byte = L_t[q_j] at its offset, and the zero-rank run behind it (the gap to the next
 //                   op's offset) is filled with the same byte (long runs by the whole wave).
-// Same results as the reference loop (:1597-1670) including its limits (run of >= 20 digits, more bytes than the block size).
-// The per-symbol bookkeeping of up to 64 symbols at once (lane d = d-th symbol in stream order): run digits -> byte counts,
-// running output offset by a wave scan, (rank, offset) of the rank symbols stored densely.  State carried between
-// calls: rank ops so far (j0), bytes so far (off), digits of the zero-rank run that is still open (run_bit).
-__device__ __forceinline__ int huff_flush(uint32_t sd, uint32_t fill, int lane, uint64_t lt, uint32_t dbuf_size, uint8_t* __restrict__ ops,
-                                          uint32_t* __restrict__ opoff, uint32_t& j0, uint32_t& off, uint32_t& run_bit) {
-  if (fill == 0) return 0;
-  const bool val = (uint32_t)lane < fill;
-  const bool isrun = val && sd <= 1u;                          // RUNA / RUNB: bijective base-2 digits of a zero-rank run (:1619-1637)
-  const uint64_t nrm = __ballot(val && !isrun);
-  const uint64_t below = nrm & lt;
-  const uint32_t digit = below ? (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(below)) - 1u : (uint32_t)lane + run_bit;
-  if (__ballot(isrun && digit >= 20u)) return CJS_E_DATA_ERROR;         // 2^20 bytes exceed every block size
-  const uint32_t c = !val ? 0u : isrun ? (sd + 1u) << digit : 1u;     // bytes this symbol emits
-  const uint32_t incl = wave_incl_sum(c);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  if (off + total > dbuf_size) return CJS_E_DATA_ERROR;                 // (:1647, :1663)
-  if (val && !isrun) {
-    const uint32_t opord = (uint32_t)__popcll(below);
-    ops[j0 + opord] = (uint8_t)(sd - 1u);
-    opoff[j0 + opord] = off + incl - c;
+// Same results as the reference loop (:1597-1670): every way it can fail there is DATA_ERROR, so a block is good iff its first
+// end-of-block symbol comes before its first undecodable code, the selectors do not run out first, and the bytes fit the block.
+struct RowTab {                    // per candidate row, in global memory between the stages
+  uint16_t fast[6][1024];
+  uint32_t first[6][22];
+  uint16_t cnt[6][22], start[6][22], bysym[6][260];
+  uint8_t minlen[8], maxlen[8];
+  uint32_t sym_total, group_count, n_sel, err;      // err: the header's verdict
+  uint64_t data_bit;               // first bit of the symbol data
+  uint32_t crc, orig;
+  uint32_t ngroups_ok;             // groups whose start bit is known (the chain's extent)
+  uint32_t pad;
+  unsigned long long eob_key;      // min over end-of-block symbols of (symbol index << 32 | bit behind the code - data_bit); ~0 = none
+  unsigned long long err_key;      // min over undecodable codes of (symbol index << 32); ~0 = none
+};
+constexpr uint32_t CH_T = 256;                  // threads of bz_chain
+constexpr uint32_t CH_SPAN = 1024;              // bit positions of a group's span (50 codes of <= 20 bits)
+constexpr uint32_t CH_ARR = CH_SPAN + 64;
+constexpr uint32_t CH_WORDS = 2048;             // 32-bit words of the stream kept in LDS (65536 bits: ~180 groups of text)
+constexpr uint32_t CH_NONE = 0xFFFFu;           // next[] of a position where no code of the table starts
+constexpr uint32_t GROUP_SYMS = 50;
+constexpr uint32_t MAX_SELECTORS = 32768;
+
+// length of the code of table g that starts with the 20 bits x (code at the top), 0 = none
+__device__ __forceinline__ uint32_t code_len20(const DecShared& S, int g, uint32_t x20) {
+  const uint32_t e = S.fast[g][x20 >> 10];
+  if (e) return e & 31u;
+  const int mx = S.maxlen[g];
+  for (int i = 11; i <= mx; i++) {              // (the 10-bit table has every code of <= 10 bits: none matched)
+    const uint32_t k = (x20 >> (20 - i)) - S.first[g][i];
+    if (k < S.cnt[g][i]) return (uint32_t)i;
   }
-  j0 += (uint32_t)__popcll(nrm);
-  off += total;
-  const uint32_t lastd = (uint32_t)__builtin_amdgcn_readlane((int)digit, fill - 1u);
-  run_bit = ((nrm >> (fill - 1u)) & 1ull) ? 0u : lastd + 1u;
-  return 0;
+  return 0u;
 }
 
-constexpr uint32_t MT_TILE = 256;
-__global__ __launch_bounds__(64) void bz_huff_ops(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
-                                                  uint8_t* __restrict__ ops_all, uint32_t* __restrict__ opoff_all, uint32_t ops_stride,
-                                                  uint8_t* __restrict__ l0_all, uint32_t* __restrict__ nops_all, BlockOut* __restrict__ outs, uint32_t row0) {
+__global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
+                                                 RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
+                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0) {
   __shared__ DecShared S;
+  __shared__ uint32_t wbuf[CH_WORDS + 2];
+  __shared__ uint16_t A[6][CH_ARR];
+  __shared__ uint8_t selc[CH_T];
+  __shared__ uint64_t s_pos;
+  __shared__ uint32_t s_hdr[8];
   const uint32_t c = blockIdx.x;
   if (c >= ncand) return;
-  const int lane = lane_id();
-  BlockOut bo; bo.end_bit = 0; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0;
-  if (cands[c].kind != 0) { if (lane == 0) { bo.end_bit = cands[c].bit + 48; outs[c] = bo; } return; }
-  const uint32_t row = cands[c].pad - row0;              // row of this batch's scratch
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (cands[c].kind != 0) {                     // end-of-stream candidate: nothing to decode
+    if (tid == 0) { BlockOut bo; bo.end_bit = cands[c].bit + 48; bo.count = 0; bo.orig = 0; bo.crc = 0; bo.err = 0; outs[c] = bo; }
+    return;
+  }
+  const uint32_t row = cands[c].pad - row0;     // row of this batch's scratch
+  RowTab& T = tabs[row];
+  uint8_t* sel = sel_all + (size_t)row * MAX_SELECTORS;
+  uint32_t* gstart = gstart_all + (size_t)row * (MAX_SELECTORS + 1);
+  const uint64_t t_k0 = wall_clock64();
+  if (tid < 64) {                               // wave 0: header, selectors, code lengths, tables
+    BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
+    uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0, crc = 0;
+    const int err = dec_prologue(S, r, dbuf_size, crc, orig, sym_total, group_count, n_sel, sel);
+    if (lane == 0) {
+      s_hdr[0] = (uint32_t)err; s_hdr[1] = sym_total; s_hdr[2] = group_count; s_hdr[3] = n_sel; s_hdr[4] = crc; s_hdr[5] = orig;
+      s_pos = r.pos;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint64_t t_hdr = wall_clock64();
+  if (tid == 0 && blockIdx.x == 0) g_dec_clk[5] = t_hdr - t_k0;
+  const int herr = (int)s_hdr[0];
+  const uint32_t group_count = s_hdr[2], n_sel = s_hdr[3];
+  const uint64_t data_bit = s_pos;
+  // the tables go to global memory for the symbol stage
+  for (uint32_t i = tid; i < 6 * 1024; i += CH_T) (&T.fast[0][0])[i] = (&S.fast[0][0])[i];
+  for (uint32_t i = tid; i < 6 * 22; i += CH_T) { (&T.first[0][0])[i] = (&S.first[0][0])[i]; (&T.cnt[0][0])[i] = (&S.cnt[0][0])[i]; (&T.start[0][0])[i] = (&S.start[0][0])[i]; }
+  for (uint32_t i = tid; i < 6 * 260; i += CH_T) (&T.bysym[0][0])[i] = (&S.bysym[0][0])[i];
+  if (tid < 8) { T.minlen[tid] = S.minlen[tid]; T.maxlen[tid] = S.maxlen[tid]; }
+  for (int i = tid; i < 256; i += CH_T) l0_all[(size_t)row * 256 + i] = S.sym_to_byte[i];
+  uint32_t ok_groups = 0;
+  if (!herr) {
+    uint64_t pos = data_bit, wbase = ~0ull;      // wbase: stream word at wbuf[0]
+    for (uint32_t k = 0; k < n_sel; k++) {
+      if ((k & (CH_T - 1)) == 0) {               // the next 256 selectors (written by lane 0 above: visible after the barrier)
+        __syncthreads();
+        selc[tid] = k + tid < n_sel ? sel[k + tid] : 0;
+        __syncthreads();
+      }
+      const int g = selc[k & (CH_T - 1)];
+      if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
+      ok_groups = k + 1;
+      const uint32_t span = min(GROUP_SYMS * (uint32_t)S.maxlen[g], CH_SPAN);
+      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + span + 64) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
+        __syncthreads();
+        wbase = pos >> 5;
+        for (uint32_t i = tid; i < CH_WORDS + 2; i += CH_T) wbuf[i] = load_be32(in, n, wbase + i);
+        __syncthreads();
+      }
+      const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
+#pragma unroll
+      for (int j = 0; j < (int)(CH_ARR + CH_T - 1) / (int)CH_T; j++) {
+        const uint32_t i = (uint32_t)tid + CH_T * j;
+        if (i < CH_ARR) {
+          uint32_t nx = CH_NONE;
+          if (i < span) {
+            const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
+            const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
+            const uint32_t len = code_len20(S, g, x20);
+            if (len) nx = i + len;
+          }
+          A[0][i] = (uint16_t)nx;
+        }
+      }
+      __syncthreads();
+      // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays
+#pragma unroll
+      for (int lv = 1; lv <= 5; lv++) {
+#pragma unroll
+        for (int j = 0; j < (int)(CH_SPAN / CH_T); j++) {
+          const uint32_t i = (uint32_t)tid + CH_T * j;
+          if (i < span) { const uint32_t v = A[lv - 1][i]; A[lv][i] = (uint16_t)(v < span ? A[lv - 1][v] : v); }
+        }
+        __syncthreads();
+      }
+      uint32_t v = A[5][0];                        // 32 codes
+      if (v < span) v = A[4][v];                   // + 16
+      if (v < span) v = A[1][v];                   // + 2
+      if (v > span) break;                         // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
+      pos += v;
+    }
+  }
+  if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
+  if (tid == 0) {
+    T.sym_total = s_hdr[1]; T.group_count = group_count; T.n_sel = n_sel; T.err = (uint32_t)herr; T.data_bit = data_bit; T.crc = s_hdr[4]; T.orig = s_hdr[5];
+    T.ngroups_ok = ok_groups; T.pad = 0; T.eob_key = ~0ull; T.err_key = ~0ull;
+  }
+}
+
+// one lane per group of 50 symbols; the block's tables in LDS
+__global__ __launch_bounds__(256) void bz_group_syms(const uint8_t* __restrict__ in, uint64_t n, RowTab* __restrict__ tabs, const uint8_t* __restrict__ sel_all,
+                                                     const uint32_t* __restrict__ gstart_all, uint16_t* __restrict__ syms_all, uint32_t sym_stride, uint32_t row0) {
+  __shared__ uint16_t fast[6][1024];
+  __shared__ uint32_t first[6][22];
+  __shared__ uint16_t cnt[6][22], start[6][22], bysym[6][260];
+  __shared__ uint8_t maxlen[8];
+  const uint32_t row = row0 + blockIdx.y;
+  RowTab& T = tabs[row];
+  const uint32_t ng = T.err ? 0u : T.ngroups_ok;
+  if (blockIdx.x * 256u >= ng) return;
+  const int tid = threadIdx.x;
+  for (uint32_t i = tid; i < 6 * 1024; i += 256) (&fast[0][0])[i] = (&T.fast[0][0])[i];
+  for (uint32_t i = tid; i < 6 * 22; i += 256) { (&first[0][0])[i] = (&T.first[0][0])[i]; (&cnt[0][0])[i] = (&T.cnt[0][0])[i]; (&start[0][0])[i] = (&T.start[0][0])[i]; }
+  for (uint32_t i = tid; i < 6 * 260; i += 256) (&bysym[0][0])[i] = (&T.bysym[0][0])[i];
+  if (tid < 8) maxlen[tid] = T.maxlen[tid];
+  __syncthreads();
+  const uint32_t k = blockIdx.x * 256u + tid;
+  if (k >= ng) return;
+  const int g = sel_all[(size_t)row * MAX_SELECTORS + k];
+  const uint32_t sym_total = T.sym_total;
+  const uint64_t data_bit = T.data_bit;
+  uint64_t pos = data_bit + gstart_all[(size_t)row * (MAX_SELECTORS + 1) + k];
+  uint16_t* syms = syms_all + (size_t)row * sym_stride;
+  const int mx = maxlen[g];
+  for (uint32_t j = 0; j < GROUP_SYMS; j++) {
+    const uint64_t idx = (uint64_t)k * GROUP_SYMS + j;
+    const uint64_t dw = pos >> 5;
+    const uint32_t w0 = load_be32(in, n, dw), w1 = load_be32(in, n, dw + 1);
+    const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (pos & 31)) >> 44);
+    uint32_t e = fast[g][x20 >> 10], sym = 0, len = 0;
+    if (e) { sym = e >> 5; len = e & 31u; }
+    else {
+      for (int i = 11; i <= mx; i++) {
+        const uint32_t q = (x20 >> (20 - i)) - first[g][i];
+        if (q < cnt[g][i]) { len = (uint32_t)i; sym = bysym[g][start[g][i] + q]; break; }
+      }
+    }
+    if (!len || idx >= sym_stride) { atomicMin(&T.err_key, (unsigned long long)idx << 32); break; }      // no code starts here (or more symbols than any block has room for)
+    pos += len;
+    if (sym > sym_total) { atomicMin(&T.eob_key, ((unsigned long long)idx << 32) | (unsigned long long)(uint32_t)(pos - data_bit)); break; }      // end of block (:1640)
+    syms[idx] = (uint16_t)sym;
+  }
+}
+
+// One workgroup per row: the symbols in front of the end-of-block symbol, 4096 per tile, front to back.
+//   RUNA (0) / RUNB (1) are the bijective base-2 digits of a zero-rank run (:1621-1638): digit d adds (sym + 1) << d bytes.  The
+//   reference keeps the digit weight in an int32 that it shifts left: the 32nd digit of a run adds (sym + 1) * -2^31, leaves the
+//   weight 0, and with it the run is forgotten (the flush at :1643 tests the weight); a 33rd digit starts a fresh run.  So the
+//   digit of a run symbol is its position in the run mod 32, and a symbol with digit 31 takes back what the 31 in front of it added.
+//   rank symbols (>= 2) emit one byte each and leave as op (rank - 1, output offset); the bytes must fit the block (:1647, :1663).
+constexpr uint32_t SO_TILE = 4096;
+__global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, const Cand* __restrict__ cands, uint32_t ncand, const uint16_t* __restrict__ syms_all,
+                                                   uint32_t sym_stride, uint32_t dbuf_size, uint8_t* __restrict__ ops_all, uint32_t* __restrict__ opoff_all,
+                                                   uint32_t ops_stride, uint32_t* __restrict__ nops_all, BlockOut* __restrict__ outs, uint32_t row0, uint64_t nbits) {
+  __shared__ uint16_t st[SO_TILE + 32];          // the tile's symbols behind the last 32 of the tile in front
+  __shared__ unsigned long long sm64[16];
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t mx[1024];
+  const uint32_t c = blockIdx.x;
+  if (c >= ncand || cands[c].kind != 0) return;
+  const uint32_t row = cands[c].pad - row0;
+  const RowTab& T = tabs[row];
+  const int tid = threadIdx.x;
+  int err = (int)T.err;
+  const unsigned long long ek = T.eob_key, xk = T.err_key;
+  if (!err && (ek == ~0ull || xk < ek)) err = CJS_E_DATA_ERROR;      // no end of block in the selectors' reach, or an undecodable code in front of it
+  const uint32_t nsym = err ? 0u : (uint32_t)(ek >> 32);
+  const uint16_t* syms = syms_all + (size_t)row * sym_stride;
   uint8_t* ops = ops_all + (size_t)row * ops_stride;
   uint32_t* opoff = opoff_all + (size_t)row * ops_stride;
-  BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
-  uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0, crc = 0;
-  int err = dec_prologue(S, r, dbuf_size, crc, orig, sym_total, group_count, n_sel);
-  uint64_t pos = r.pos;
-  for (int i = lane; i < 256; i += 64) l0_all[(size_t)row * 256 + i] = S.sym_to_byte[i];
-  uint32_t off = 0, j0 = 0;
-  if (!err) {
-    BitWin bw{in, n, 0, 0, 0};
-    bw.init(pos, lane);
-    // Per round (64 bit positions): (1) every lane looks up the code that WOULD start at bit pos + lane; (2) the serial
-    // part is only the walk from code start to code start -- one readlane + add + bit-set per symbol; (3) everything per
-    // symbol (end-of-block test, run digits, output offsets, op compaction) is done across the lanes, for 64 buffered
-    // symbols at a time.  A lone wave issues about one instruction per 8 cycles, so the instruction count of the round is
-    // what is kept small here (a four-window variant with straight-line hops had more of them and was no faster).
-    uint32_t selector = 0, sym_left = 0, run_bit = 0; int g = 0;      // run_bit: digits of the zero-rank run that is still open
-    const uint64_t t_p0 = wall_clock64();
-    const uint64_t lane_bit = 1ull << lane, lt = lane_bit - 1ull;
-    bool done = false, slow = false;
-    uint32_t bufv = 0, fill = 0;
-    while (!done && !err) {
-      if (sym_left == 0) {
-        sym_left = 50;
-        if (selector >= n_sel) { err = CJS_E_DATA_ERROR; break; }
-        g = __builtin_amdgcn_readfirstlane((int)S.selectors[selector++]);
-        if ((uint32_t)g >= group_count) { err = CJS_E_DATA_ERROR; break; }
-      }
-      bw.ensure(pos, lane);
-      uint64_t mask = 0; uint32_t sym_l, len_l, adv;
-      if (!slow) {
-        const uint32_t d = (uint32_t)((pos >> 5) - bw.base);
-        const uint32_t w0 = bw.word(d), w1 = bw.word(d + 1), w2 = bw.word(d + 2), w3 = bw.word(d + 3);
-        const uint32_t o = (uint32_t)(pos & 31) + (uint32_t)lane, wi = o >> 5;
-        const uint32_t hi = wi == 0 ? w0 : wi == 1 ? w1 : w2, lo = wi == 0 ? w1 : wi == 1 ? w2 : w3;
-        const uint32_t x = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31)) >> 54);
-        const uint32_t e = S.fast[g][x];
-        len_l = e & 31u; sym_l = e >> 5;
-        const uint32_t step = e == 0u ? 64u : len_l;                       // a code the 10-bit table cannot decode ends the walk
-        uint32_t idx = 0;
-        do {                                                             // the serial chain: code start -> next code start
-          mask |= 1ull << idx;
-          idx += (uint32_t)__builtin_amdgcn_readlane((int)step, idx);
-        } while (idx < 64u);
-        // the group's table holds for sym_left more symbols only
-        if ((uint32_t)__popcll(mask) > sym_left) mask = __ballot((mask & lane_bit) != 0 && (uint32_t)__popcll(mask & lt) < sym_left);
-        // the round ends behind its last symbol -- unless that one needs the bit-by-bit rule, then in front of it
-        const uint32_t ll = 63u - (uint32_t)__builtin_clzll(mask);
-        const uint32_t stl = (uint32_t)__builtin_amdgcn_readlane((int)step, ll);
-        if (stl == 64u) { mask &= ~(1ull << ll); adv = ll; slow = true; }
-        else adv = ll + stl;
-      } else {
-        int i = __builtin_amdgcn_readfirstlane((int)S.minlen[g]);            // a code of more than 10 bits: one bit at a time (the decisions of :1605-1616)
-        const int mx = __builtin_amdgcn_readfirstlane((int)S.maxlen[g]);
-        uint32_t j = bw.peek(pos, i), k = 0;
-        for (;; i++) {
-          if (i > mx) { err = CJS_E_DATA_ERROR; break; }                       // no code of this table starts here
-          k = j - (uint32_t)__builtin_amdgcn_readfirstlane(S.first[g][i]);
-          if (k < (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)S.cnt[g][i])) break;
-          j = (j << 1) | bw.peek(pos + i, 1);
+  unsigned long long off = 0;                    // bytes so far
+  uint32_t j0 = 0, last_nonrun = 0;              // ops so far; (index of the last rank symbol so far) + 1
+  if (tid < 32) st[tid] = 2;                     // in front of the first symbol: not a run
+  for (uint32_t base = 0; base < nsym && !err; base += SO_TILE) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t i = base + (uint32_t)tid * 4u + q; st[32 + tid * 4 + q] = i < nsym ? syms[i] : (uint16_t)2; }
+    __syncthreads();
+    // position in the run: i - (index of the last rank symbol in front of i) - 1, by a max scan of (index + 1) of the rank symbols
+    uint32_t lastb = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t i = base + (uint32_t)tid * 4u + q; if (i < nsym && st[32 + tid * 4 + q] >= 2) lastb = i + 1; }
+    const uint32_t incl = block_incl_max<1024>(lastb, sm);
+    mx[tid] = incl;
+    __syncthreads();
+    uint32_t prevnr = tid ? mx[tid - 1] : 0u;
+    const uint32_t tile_last = mx[1023];
+    __syncthreads();
+    if (prevnr < last_nonrun) prevnr = last_nonrun;
+    long long cb[4]; unsigned long long mine = 0; uint32_t nops = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t i = base + (uint32_t)tid * 4u + q, sy = st[32 + tid * 4 + q];
+      cb[q] = 0;
+      if (i < nsym) {
+        if (sy >= 2) { cb[q] = 1; nops++; prevnr = i + 1; }
+        else {
+          const uint32_t d = (i - prevnr) & 31u;
+          if (d < 31) cb[q] = (long long)(sy + 1u) << d;
+          else { long long t = 0; for (uint32_t b = 1; b <= 31; b++) t += (long long)((uint32_t)st[32 + tid * 4 + q - b] + 1u) << (31u - b); cb[q] = -t; }
         }
-        if (err) break;
-        sym_l = __builtin_amdgcn_readfirstlane((uint32_t)S.bysym[g][(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)S.start[g][i]) + k]);
-        len_l = (uint32_t)i; mask = 1ull; adv = (uint32_t)i; slow = false;
       }
-      // end of block inside this round?  (:1640)  symbols behind it are not symbols
-      const uint64_t eobm = __ballot((mask & lane_bit) != 0 && sym_l > sym_total);
-      if (eobm) {
-        const uint32_t first = (uint32_t)__builtin_ctzll(eobm);
-        mask &= (1ull << first) - 1ull;
-        adv = first + (uint32_t)__builtin_amdgcn_readlane((int)len_l, first);
-        done = true; slow = false;
-      }
-      const uint32_t cnt = (uint32_t)__popcll(mask);
-      if (cnt) {
-        // the round's symbols join a 64-entry buffer (lane = arrival order); the bookkeeping runs when it is full
-        if (fill + cnt > 64u) { err = huff_flush(bufv, fill, lane, lt, dbuf_size, ops, opoff, j0, off, run_bit); fill = 0; if (err) break; }
-        const uint32_t ord = fill + (uint32_t)__popcll(mask & lt);
-        // (lanes that hold no symbol aim at a lane outside [fill, fill + cnt): the one behind it, or lane 0 < fill when it ends at 63)
-        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(((mask & lane_bit) ? ord : ((fill + cnt) & 63u)) << 2), (int)sym_l);
-        bufv = ((uint32_t)lane >= fill && (uint32_t)lane < fill + cnt) ? got : bufv;
-        fill += cnt;
-        sym_left -= done ? 0u : cnt;
-      }
-      pos += adv;
+      mine += (unsigned long long)cb[q];
     }
-    if (!err) err = huff_flush(bufv, fill, lane, lt, dbuf_size, ops, opoff, j0, off, run_bit);
-    if (lane == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_p0; g_dec_clk[7] = j0; }
+    unsigned long long tot;
+    unsigned long long ex = off + block_excl_sum<1024>(mine, sm64, tot);
+    uint32_t ntot;
+    uint32_t jx = j0 + block_excl_sum<1024>(nops, sm, ntot);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t i = base + (uint32_t)tid * 4u + q, sy = st[32 + tid * 4 + q];
+      if (i < nsym && sy >= 2) {
+        if (jx < ops_stride - 1u && ex < 0xFFFFFFFFull) { ops[jx] = (uint8_t)(sy - 2u); opoff[jx] = (uint32_t)ex; }
+        jx++;
+      }
+      ex += (unsigned long long)cb[q];
+    }
+    off += tot; j0 += ntot;                       // (off may hold digits of a run that is still open: the byte limit is tested at the end)
+    if (tile_last > last_nonrun) last_nonrun = tile_last;
+    if (j0 >= ops_stride - 1u) err = CJS_E_DATA_ERROR;                           // (uniform) more rank symbols than the block has bytes
+    __syncthreads();
+    if (tid < 32) st[tid] = st[SO_TILE + tid];   // the last 32 symbols stay in front of the next tile
   }
-  err = __builtin_amdgcn_readfirstlane(err);
-  if (err) { j0 = 0; off = 0; }
-  if (!err && orig >= off) err = CJS_E_DATA_ERROR;            // :1677
-  if (lane == 0) {
-    opoff[j0] = off;                                         // the end-of-block pseudo op: where the output ends
+  // Offsets at rank symbols never decrease, so every "fits the block" test of the reference (:1647 before a flush, :1663 before
+  // a literal) passes iff the final byte count does
+  if (!err && off > dbuf_size) err = CJS_E_DATA_ERROR;
+  if (!err && T.orig >= off) err = CJS_E_DATA_ERROR;                            // :1677
+  if (tid == 0) {
+    if (err) { j0 = 0; off = 0; }
+    opoff[j0] = (uint32_t)off;                   // the end-of-block pseudo op: where the output ends
     nops_all[row] = j0;
-    bo.end_bit = pos > n * 8 ? n * 8 : pos; bo.count = err ? 0u : off; bo.orig = orig; bo.crc = crc; bo.err = err;
+    BlockOut bo;
+    const uint64_t endb = T.data_bit + (uint32_t)ek;
+    bo.end_bit = err ? 0 : (endb > nbits ? nbits : endb);
+    bo.count = err ? 0u : (uint32_t)off; bo.orig = T.orig; bo.crc = T.crc; bo.err = err;
     outs[c] = bo;
   }
 }
 
+constexpr uint32_t MT_TILE = 256;
 // grid = (tile groups, rows of a slab): rows come in slabs of <= 65535 (grid.y), and a grid may not exceed 2^32 threads in all
 __global__ __launch_bounds__(256) void bz_mtf_tiles(uint8_t* __restrict__ ops_all, uint32_t ops_stride, const uint32_t* __restrict__ nops_all,
                                                     uint8_t* __restrict__ pl_all, uint32_t tiles_per_row, uint32_t row0) {
@@ -919,10 +1058,13 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   const uint32_t dsz = J->tt_stride;
   const uint32_t ops_stride = (dsz + 256u + 255u) & ~255u, tiles_per_row = ops_stride / MT_TILE;
   static const uint64_t budget = getenv("CJS_DEC_ROW_BYTES") ? strtoull(getenv("CJS_DEC_ROW_BYTES"), nullptr, 10) : (8ull << 30);      // (tests shrink it)
-  const uint64_t per_row = (uint64_t)dsz + 6ull * ops_stride + 256 + 4;
+  const uint32_t sym_stride = dsz + 4096u;                              // symbols in front of the end of block: each emits a byte (but for forgotten runs), so <= dsz
+  const uint32_t group_tiles = (std::min<uint32_t>(MAX_SELECTORS, sym_stride / GROUP_SYMS + 1u) + 255u) / 256u;
+  const uint64_t per_row = (uint64_t)dsz + 6ull * ops_stride + 256 + 4 + sizeof(RowTab) + MAX_SELECTORS + 4ull * (MAX_SELECTORS + 1) + 2ull * sym_stride;
   const uint32_t nr = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nrows ? nrows : 1u, 65535u), std::max<uint64_t>(1ull, budget / per_row)));      // (<= grid.y)
   const bool single = nrows <= nr;
-  uint8_t *d_ttb = nullptr, *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr; RowDst* d_gdst = nullptr;
+  uint8_t *d_ttb = nullptr, *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr, *d_sel = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr, *d_gstart = nullptr;
+  RowDst* d_gdst = nullptr; RowTab* d_tabs = nullptr; uint16_t* d_syms = nullptr;
   rc = S->take((void**)&d_ttb, (size_t)nr * dsz);
   if (!rc) rc = S->take((void**)&d_bo, sizeof(BlockOut) * ncand);
   if (!rc) rc = S->take((void**)&d_ops, (size_t)nr * ops_stride);
@@ -930,6 +1072,10 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (!rc) rc = S->take((void**)&d_l0, (size_t)nr * 256);
   if (!rc) rc = S->take((void**)&d_pl, (size_t)nr * ops_stride);
   if (!rc) rc = S->take((void**)&d_nops, 4 * (size_t)nr);
+  if (!rc) rc = S->take((void**)&d_tabs, sizeof(RowTab) * (size_t)nr);
+  if (!rc) rc = S->take((void**)&d_sel, (size_t)MAX_SELECTORS * nr);
+  if (!rc) rc = S->take((void**)&d_gstart, 4 * (size_t)(MAX_SELECTORS + 1) * nr);
+  if (!rc) rc = S->take((void**)&d_syms, 2 * (size_t)sym_stride * nr);
   if (!rc && !single) rc = S->take((void**)&d_gdst, sizeof(RowDst) * (size_t)nr);
   if (rc) { S->rc = rc; return; }
   if (single) S->d_tt = d_ttb;
@@ -939,8 +1085,9 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     uint32_t c1 = c0, rows = 0, r0 = 0;
     while (c1 < ncand && (S->cands[c1].kind != 0 || rows < nr)) { if (S->cands[c1].kind == 0) { if (!rows) r0 = S->cands[c1].pad; rows++; } c1++; }
     const uint32_t nc = c1 - c0;
-    if (rows && hipMemsetAsync(d_nops, 0, 4 * (size_t)rows, s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
-    hipLaunchKernelGGL(bz_huff_ops, dim3(nc), dim3(64), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_ops, d_opoff, ops_stride, d_l0, d_nops, d_bo + c0, r0);
+    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0);
+    if (rows) hipLaunchKernelGGL(bz_group_syms, dim3(group_tiles, rows), dim3(256), 0, s, S->d_in, S->up_hi, d_tabs, d_sel, d_gstart, d_syms, sym_stride, 0u);
+    hipLaunchKernelGGL(bz_sym_ops, dim3(nc), dim3(1024), 0, s, d_tabs, d_cand + c0, nc, d_syms, sym_stride, dsz, d_ops, d_opoff, ops_stride, d_nops, d_bo + c0, r0, S->up_hi * 8);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data() + c0, d_bo + c0, sizeof(BlockOut) * nc, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
     uint32_t maxc = 0; uint64_t packed = 0;
@@ -975,12 +1122,12 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     }
     c0 = c1;
   }
-  S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops);
+  S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops); S->drop(d_tabs); S->drop(d_sel); S->drop(d_gstart); S->drop(d_syms);
   if (!single) { S->drop(d_ttb); S->drop(d_gdst); }
   if (getenv("CJS_DEBUG")) {
     uint64_t clk[8];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
-      fprintf(stderr, "[cjs dec] candidate 0: Huffman chain %.1f us for %llu rank ops\n", clk[6] / 100.0, (unsigned long long)clk[7]);
+      fprintf(stderr, "[cjs dec] candidate 0: header + tables %.1f us, group chain %.1f us for %llu groups\n", clk[5] / 100.0, clk[6] / 100.0, (unsigned long long)clk[7]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
             (unsigned long long)S->hi, (unsigned long long)S->up_lo, (unsigned long long)S->up_hi, up_n, ncand);

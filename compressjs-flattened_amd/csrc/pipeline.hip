@@ -186,9 +186,10 @@ static int blocks_through_tables(cjs_ctx* c, const uint8_t* d_in, size_t n, uint
   // The suffix sort keeps the memory system busy and the SIMDs idle; MTF / RLE2 and the Huffman tables are latency-bound chains
   // of small kernels that leave the memory system idle.  So the blocks go in `pieces` runs: while the sort of piece i + 1 runs on
   // the work stream, MTF and the tables of piece i run beside it on the tail stream (per-stage times: one piece, one stream).
-  static const uint32_t env_pieces = getenv("CJS_PIECES") ? (uint32_t)atoi(getenv("CJS_PIECES")) : 2u;
-  uint32_t pieces = stage_times || !c->tail ? 1u : std::min<uint32_t>(std::min<uint32_t>(env_pieces, 8u), cnt / 16u);     // (a piece of < 16 blocks does not fill the chip)
-  if (pieces < 1) pieces = 1;
+  // Every piece pays the sort's ~90 launches again (each followed by ~6 us in which its write-back drains, and the tail rounds are
+  // launch-bound whatever the piece holds): 100 MB in 2 / 3 / 4 pieces 12.5 / 13.2 / 14.2 ms against 11.7 in one; 2^30 bytes
+  // (1,194 blocks) in 1 / 2 / 4 / 8 pieces 117.4 / 111.4 / 109.4 / 111.6 ms.  So: four pieces from 512 blocks on.
+  const uint32_t pieces = (stage_times || !c->tail || cnt < 512u) ? 1u : 4u;
   if (cnt && pieces == 1) {
     if (stage_times) c->timer.start();
     CJS_TRY(bwt_run(s, c->bwt, c->d_blocks, cnt, c->cap, n_last, true, c->d_U, c->d_pidx, st, stage_times));
