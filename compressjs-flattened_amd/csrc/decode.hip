@@ -106,8 +106,11 @@ struct DecShared {
   uint16_t fast[6][1024];          // (sym << 5) | len, 0 = not decodable within 10 bits
   uint8_t minlen[8], maxlen[8];
   uint8_t length[6][260];
-  uint8_t mtf[8];
   uint8_t sym_to_byte[256];
+  // left-justified (20-bit) end of the codes of each length, for the branch-free length rule of bz_chain: the code that starts
+  // with the 20 bits x has length 1 + #{L in 1..19 : x >= limp[L]} and exists iff x < limp[20]  (limp[L] = 0 below the shortest
+  // length, = (first[L] + cnt[L]) << (20 - L) from there to the longest, then 2^20 up to L = 19; limp[20] = the longest's)
+  uint32_t limp[6][21];
 };
 
 // big-endian 32-bit word `dw` of the stream, zeros past the end (the reference's reader yields zero bits there, :149)
@@ -136,10 +139,10 @@ struct BitWin {
   }
 };
 
-// Block header, selector list, code lengths (lane 0, serial) and the decode tables (whole wave).  Executed by ONE wave;
-// the results are wave-uniform scalars.  Returns 0 or a CJS_E_* code.
+// Block header and code lengths (lane 0, serial), selector list and decode tables (whole wave).  Executed by ONE wave; the results
+// are wave-uniform scalars.  Returns 0 or a CJS_E_* code.  `selp`: LDS scratch of 4096 words (the unary values, a nibble each).
 __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint32_t& crc, uint32_t& orig, uint32_t& sym_total,
-                            uint32_t& group_count, uint32_t& n_sel, uint8_t* __restrict__ selectors /* global, room for 32768 */) {
+                            uint32_t& group_count, uint32_t& n_sel, uint8_t* __restrict__ selectors /* global, room for 32768 */, uint32_t* __restrict__ selp) {
   int err = 0;
   sym_total = 0; group_count = 0; n_sel = 0; orig = 0;
   const int lane = lane_id();
@@ -158,18 +161,64 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     if (!err && (group_count < 2 || group_count > 6)) err = CJS_E_DATA_ERROR;
     n_sel = r.get(15);
     if (!err && n_sel == 0) err = CJS_E_DATA_ERROR;
-    if (!err) {
-      for (uint32_t i = 0; i < 8; i++) S.mtf[i] = (uint8_t)i;
-      for (uint32_t i = 0; i < n_sel && !err; i++) {
-        uint32_t j = 0;
-        while (r.get(1)) { if (j >= group_count) { err = CJS_E_DATA_ERROR; break; } j++; }
-        if (err) break;
-        const uint8_t v = S.mtf[j];
-        for (uint32_t k = j; k > 0; k--) S.mtf[k] = S.mtf[k - 1];
-        S.mtf[0] = v;
-        selectors[i] = v;
+  }
+  err = __builtin_amdgcn_readfirstlane(err);
+  group_count = __builtin_amdgcn_readfirstlane(group_count); n_sel = __builtin_amdgcn_readfirstlane(n_sel);
+  uint64_t pos = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
+  if (!err) {
+    // Selector list (:1487-1493): n_sel unary numbers (ones closed by a zero).  Every lane takes 32 bits of a 2048-bit stretch:
+    // its zeros are selector ends, the ones in front of a zero (back to the previous zero, which may sit in the lane before) the
+    // value.  A value may equal group_count (the reference tests the count BEFORE it reads on: j ones pass for j <= group_count,
+    // and its list holds zeros behind the groups); one more is an error.
+    for (uint32_t i = lane; i < (n_sel + 7) / 8; i += 64) selp[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t nbytes = (r.nbits + 7) >> 3;
+    uint32_t done = 0, carry = 0; int bad = 0; uint64_t endpos = pos;
+    while (done < n_sel) {
+      const uint64_t bp = pos + 32u * (uint32_t)lane;
+      const uint32_t w0 = load_be32(r.p, nbytes, bp >> 5), w1 = load_be32(r.p, nbytes, (bp >> 5) + 1);
+      const uint32_t v = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (bp & 31)) >> 32);
+      const uint32_t nz = (uint32_t)__builtin_popcount(~v);
+      const uint32_t incl = wave_incl_sum(nz), excl = incl - nz;
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const uint32_t t1 = v == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~v);      // ones at the end of my word (32: all of it -- more than any value)
+      uint32_t pend = (uint32_t)__shfl_up((int)t1, 1, 64);
+      if (lane == 0) pend = carry;
+      uint32_t z = ~v, k = done + excl; int prevb = -1 - (int)pend;
+      while (z && k < n_sel) {
+        const int bidx = __builtin_clz(z);
+        const uint32_t j = (uint32_t)(bidx - prevb - 1);
+        if (j > group_count) bad = 1;
+        else atomicOr(&selp[k >> 3], j << (4u * (k & 7u)));
+        if (k + 1 == n_sel) endpos = bp + (uint32_t)bidx + 1u;
+        z &= ~(0x80000000u >> bidx); prevb = bidx; k++;
       }
+      if (done + total >= n_sel) {                                       // the lane that holds the last selector knows where the list ends
+        const uint64_t m = __ballot(done + incl >= n_sel);
+        const int l = (int)__builtin_ctzll(m);
+        endpos = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)endpos, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(endpos >> 32), l) << 32);
+        done = n_sel;
+      } else { done += total; carry = (uint32_t)__builtin_amdgcn_readlane((int)t1, 63); pos += 2048; }
     }
+    if (__ballot(bad != 0)) err = CJS_E_DATA_ERROR;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      if (!err) {                                            // move-to-front over the values: the list as nibbles of one register
+        uint32_t st = 0;
+        for (uint32_t i = 0; i < group_count; i++) st |= i << (4u * i);
+        uint32_t wv = 0;
+        for (uint32_t i = 0; i < n_sel; i++) {
+          if ((i & 7u) == 0) wv = selp[i >> 3];
+          const uint32_t j = wv & 15u; wv >>= 4;
+          const uint32_t val = (st >> (4u * j)) & 15u, low = st & ((1u << (4u * j)) - 1u);
+          st = (st & ~((1u << (4u * j + 4u)) - 1u)) | (low << 4) | val;
+          selectors[i] = (uint8_t)val;
+        }
+      }
+      r.pos = endpos > r.nbits ? r.nbits : endpos;
+    }
+  }
+  if (lane == 0) {
     if (!err) {                                              // code lengths (:1500-1520)
       const uint32_t sym_count = sym_total + 2;
       for (uint32_t g = 0; g < group_count && !err; g++) {
@@ -207,6 +256,11 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
         code = (code + S.cnt[g][l]) << 1;
       }
       for (uint32_t i = 0; i < sym_count; i++) S.bysym[g][fillp[S.length[g][i]]++] = (uint16_t)i;
+      for (int l = 1; l <= 20; l++) {
+        const uint32_t lj = l < mn ? 0u : l <= mx ? (S.first[g][l] + S.cnt[g][l]) << (20 - l) : (1u << 20);
+        S.limp[g][l] = l == 20 ? (mx == 20 ? lj : (S.first[g][mx] + S.cnt[g][mx]) << (20 - mx)) : (l < mx ? lj : (l >= mn ? (1u << 20) : 0u));
+      }
+      S.limp[g][0] = 0;
     }
     __builtin_amdgcn_wave_barrier();
     // 10-bit direct tables: entry x = the code that is a prefix of the 10 bits x, if it has one of <= 10 bits
@@ -264,7 +318,7 @@ struct RowTab {                    // per candidate row, in global memory betwee
   unsigned long long eob_key;      // min over end-of-block symbols of (symbol index << 32 | bit behind the code - data_bit); ~0 = none
   unsigned long long err_key;      // min over undecodable codes of (symbol index << 32); ~0 = none
 };
-constexpr uint32_t CH_T = 256;                  // threads of bz_chain
+constexpr uint32_t CH_T = 1024;                 // threads of bz_chain: one per bit position of the span
 constexpr uint32_t CH_SPAN = 1024;              // bit positions of a group's span (50 codes of <= 20 bits)
 constexpr uint32_t CH_ARR = CH_SPAN + 64;
 constexpr uint32_t CH_WORDS = 2048;             // 32-bit words of the stream kept in LDS (65536 bits: ~180 groups of text)
@@ -272,24 +326,14 @@ constexpr uint32_t CH_NONE = 0xFFFFu;           // next[] of a position where no
 constexpr uint32_t GROUP_SYMS = 50;
 constexpr uint32_t MAX_SELECTORS = 32768;
 
-// length of the code of table g that starts with the 20 bits x (code at the top), 0 = none
-__device__ __forceinline__ uint32_t code_len20(const DecShared& S, int g, uint32_t x20) {
-  const uint32_t e = S.fast[g][x20 >> 10];
-  if (e) return e & 31u;
-  const int mx = S.maxlen[g];
-  for (int i = 11; i <= mx; i++) {              // (the 10-bit table has every code of <= 10 bits: none matched)
-    const uint32_t k = (x20 >> (20 - i)) - S.first[g][i];
-    if (k < S.cnt[g][i]) return (uint32_t)i;
-  }
-  return 0u;
-}
 
 __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
                                                  uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0) {
   __shared__ DecShared S;
-  __shared__ uint32_t wbuf[CH_WORDS + 2];
-  __shared__ uint16_t A[6][CH_ARR];
+  __shared__ uint32_t scratch[6 * CH_ARR / 2 + CH_WORDS + 2];          // the prologue's selector values (4096 words), then the chain's arrays
+  uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);
+  uint32_t* wbuf = scratch + 6 * CH_ARR / 2;
   __shared__ uint8_t selc[CH_T];
   __shared__ uint64_t s_pos;
   __shared__ uint32_t s_hdr[8];
@@ -308,7 +352,7 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   if (tid < 64) {                               // wave 0: header, selectors, code lengths, tables
     BitReader r{in, n * 8, cands[c].bit + 48, 0, ~0ull >> 4};
     uint32_t sym_total = 0, group_count = 0, n_sel = 0, orig = 0, crc = 0;
-    const int err = dec_prologue(S, r, dbuf_size, crc, orig, sym_total, group_count, n_sel, sel);
+    const int err = dec_prologue(S, r, dbuf_size, crc, orig, sym_total, group_count, n_sel, sel, scratch);
     if (lane == 0) {
       s_hdr[0] = (uint32_t)err; s_hdr[1] = sym_total; s_hdr[2] = group_count; s_hdr[3] = n_sel; s_hdr[4] = crc; s_hdr[5] = orig;
       s_pos = r.pos;
@@ -347,29 +391,27 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         __syncthreads();
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
+      {
+        // the length of the code that would start at bit i of the span: 1 + the number of lengths whose codes all lie below the 20
+        // bits found there (no table lookup, no branch: at an arbitrary bit offset every twentieth position or so starts no short code)
+        const uint32_t i = (uint32_t)tid;
+        uint32_t nx = CH_NONE;
+        if (i < span) {
+          const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
+          const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
+          uint32_t len = 1;
 #pragma unroll
-      for (int j = 0; j < (int)(CH_ARR + CH_T - 1) / (int)CH_T; j++) {
-        const uint32_t i = (uint32_t)tid + CH_T * j;
-        if (i < CH_ARR) {
-          uint32_t nx = CH_NONE;
-          if (i < span) {
-            const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
-            const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-            const uint32_t len = code_len20(S, g, x20);
-            if (len) nx = i + len;
-          }
-          A[0][i] = (uint16_t)nx;
+          for (int l = 1; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
+          if (x20 < S.limp[g][20]) nx = i + len;
         }
+        A[0][i] = (uint16_t)nx;
+        if (tid < CH_ARR - CH_T) A[0][CH_T + tid] = (uint16_t)CH_NONE;
       }
       __syncthreads();
       // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays
 #pragma unroll
       for (int lv = 1; lv <= 5; lv++) {
-#pragma unroll
-        for (int j = 0; j < (int)(CH_SPAN / CH_T); j++) {
-          const uint32_t i = (uint32_t)tid + CH_T * j;
-          if (i < span) { const uint32_t v = A[lv - 1][i]; A[lv][i] = (uint16_t)(v < span ? A[lv - 1][v] : v); }
-        }
+        if ((uint32_t)tid < span) { const uint32_t v = A[lv - 1][tid]; A[lv][tid] = (uint16_t)(v < span ? A[lv - 1][v] : v); }
         __syncthreads();
       }
       uint32_t v = A[5][0];                        // 32 codes
@@ -499,7 +541,7 @@ __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, co
     for (int q = 0; q < 4; q++) {
       const uint32_t i = base + (uint32_t)tid * 4u + q, sy = st[32 + tid * 4 + q];
       if (i < nsym && sy >= 2) {
-        if (jx < ops_stride - 1u && ex < 0xFFFFFFFFull) { ops[jx] = (uint8_t)(sy - 2u); opoff[jx] = (uint32_t)ex; }
+        if (jx < ops_stride - 1u && ex < 0xFFFFFFFFull) { ops[jx] = (uint8_t)(sy - 1u); opoff[jx] = (uint32_t)ex; }      // rank symbol s reads list slot s - 1 (:1664)
         jx++;
       }
       ex += (unsigned long long)cb[q];
