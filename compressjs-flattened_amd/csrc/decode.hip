@@ -321,6 +321,7 @@ struct RowTab {                    // per candidate row, in global memory betwee
 constexpr uint32_t CH_T = 1024;                 // threads of bz_chain: one per bit position of the span
 constexpr uint32_t CH_SPAN = 1024;              // bit positions of a group's span (50 codes of <= 20 bits)
 constexpr uint32_t CH_ARR = CH_SPAN + 64;
+constexpr uint32_t CH_SHORT = 512;              // positions of a step's first attempt
 constexpr uint32_t CH_WORDS = 2048;             // 32-bit words of the stream kept in LDS (65536 bits: ~180 groups of text)
 constexpr uint32_t CH_NONE = 0xFFFFu;           // next[] of a position where no code of the table starts
 constexpr uint32_t GROUP_SYMS = 50;
@@ -383,14 +384,20 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       const int g = selc[k & (CH_T - 1)];
       if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
       ok_groups = k + 1;
-      const uint32_t span = min(GROUP_SYMS * (uint32_t)S.maxlen[g], CH_SPAN);
-      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + span + 64) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
+      // The span that is safe for any 50 codes (50 x the longest) is about three times what 50 codes of text take (~360 bits), and
+      // the rounds below are bound by LDS gathers per position: the first attempt works on CH_SHORT positions; a chain that leaves
+      // them (or meets a position where no code starts) is worked out again on the whole span.
+      const uint32_t full_span = min(GROUP_SYMS * (uint32_t)S.maxlen[g], CH_SPAN);
+      uint32_t span = min(full_span, CH_SHORT);
+      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + full_span + 64) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
         __syncthreads();
         wbase = pos >> 5;
         for (uint32_t i = tid; i < CH_WORDS + 2; i += CH_T) wbuf[i] = load_be32(in, n, wbase + i);
         __syncthreads();
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
+      uint32_t v = CH_NONE;
+      for (int attempt = 0; attempt < 2; attempt++) {                      // (uniform)
       {
         // the length of the code that would start at bit i of the span: 1 + the number of lengths whose codes all lie below the 20
         // bits found there (no table lookup, no branch: at an arbitrary bit offset every twentieth position or so starts no short code)
@@ -404,8 +411,8 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
           for (int l = 1; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
           if (x20 < S.limp[g][20]) nx = i + len;
         }
-        A[0][i] = (uint16_t)nx;
-        if (tid < CH_ARR - CH_T) A[0][CH_T + tid] = (uint16_t)CH_NONE;
+        if (i < span + 64u) A[0][i] = (uint16_t)nx;
+        if (tid < 64 && CH_T + (uint32_t)tid < span + 64u) A[0][CH_T + tid] = (uint16_t)CH_NONE;
       }
       __syncthreads();
       // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays
@@ -414,9 +421,13 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         if ((uint32_t)tid < span) { const uint32_t v = A[lv - 1][tid]; A[lv][tid] = (uint16_t)(v < span ? A[lv - 1][v] : v); }
         __syncthreads();
       }
-      uint32_t v = A[5][0];                        // 32 codes
+      v = A[5][0];                                 // 32 codes
       if (v < span) v = A[4][v];                   // + 16
       if (v < span) v = A[1][v];                   // + 2
+      if (v <= span || span == full_span) break;
+      span = full_span;
+      __syncthreads();                             // (everyone has read the short attempt's arrays)
+      }
       if (v > span) break;                         // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
       pos += v;
     }

@@ -188,8 +188,8 @@ static int blocks_through_tables(cjs_ctx* c, const uint8_t* d_in, size_t n, uint
   // the work stream, MTF and the tables of piece i run beside it on the tail stream (per-stage times: one piece, one stream).
   // Every piece pays the sort's ~90 launches again (each followed by ~6 us in which its write-back drains, and the tail rounds are
   // launch-bound whatever the piece holds): 100 MB in 2 / 3 / 4 pieces 12.5 / 13.2 / 14.2 ms against 11.7 in one; 2^30 bytes
-  // (1,194 blocks) in 1 / 2 / 4 / 8 pieces 117.4 / 111.4 / 109.4 / 111.6 ms.  So: four pieces from 512 blocks on.
-  const uint32_t pieces = (stage_times || !c->tail || cnt < 512u) ? 1u : 4u;
+  // (1,194 blocks) in 1 / 2 / 4 / 8 pieces 117.4 / 111.4 / 109.4 / 111.6 ms.  So: four pieces from 400 MB of blocks on.
+  const uint32_t pieces = (stage_times || !c->tail || (uint64_t)cnt * c->cap < 400000000ull) ? 1u : 4u;
   if (cnt && pieces == 1) {
     if (stage_times) c->timer.start();
     CJS_TRY(bwt_run(s, c->bwt, c->d_blocks, cnt, c->cap, n_last, true, c->d_U, c->d_pidx, st, stage_times));

@@ -357,7 +357,16 @@ __device__ SpecOut spec_boundary_group(const uint8_t* __restrict__ in, uint64_t 
   tt = __shfl(tt, fl, 32); accv = (uint32_t)__shfl((int)accv, fl, 32); cv = (uint32_t)__shfl((int)cv, fl, 32);
   const uint64_t pe = p0 + 8u * (uint32_t)fl + (uint32_t)tt;
   o.e = pe + 1;
-  const bool next_fresh = pe + 1 >= N || in[pe + 1] != (uint8_t)cv;
+  bool next_fresh = pe + 1 >= N || in[pe + 1] != (uint8_t)cv;
+  if (!next_fresh) {
+    // the next block starts inside a run -- but a run of at most three bytes is all literals under either chunking (the one
+    // counted from the run start and the one that starts afresh with the block), so the boundaries behind it are where the
+    // speculation expects them: as good as a block start on a run boundary.  (text: "ll", "ee" at a block end)
+    const uint8_t b = (uint8_t)cv;
+    const uint32_t left = (pe >= 1 && in[pe - 1] == b) ? ((pe >= 2 && in[pe - 2] == b) ? 2u : 1u) : 0u;
+    const uint32_t right = 1u + ((pe + 2 < N && in[pe + 2] == b) ? ((pe + 3 < N && in[pe + 3] == b) ? 2u : 1u) : 0u);
+    next_fresh = 1u + left + right <= 3u;
+  }
   o.clean = (accv == rel) && next_fresh;
   return o;
 }
