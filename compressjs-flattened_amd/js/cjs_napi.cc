@@ -52,7 +52,14 @@ bool load_api() {
   return true;
 }
 
-void finalize_buf(napi_env, void* data, void*) { if (api.free_) api.free_(data); }
+// Results are handed to JS as EXTERNAL ArrayBuffers over the library's (pinned, pooled) result buffers; V8 is told how much
+// memory hangs on each one, so that it collects dropped results soon and their buffers go back to the pool instead of a new
+// pinned buffer being made for every call (hipHostMalloc of a 32 MB result costs more than compressing 50 MB).
+void finalize_buf(napi_env env, void* data, void* hint) {
+  if (api.free_) api.free_(data);
+  int64_t adj = 0;
+  napi_adjust_external_memory(env, -(int64_t)(intptr_t)hint, &adj);
+}
 
 napi_value throw_code(napi_env env, int code) {
   napi_value err, msg, num;
@@ -87,7 +94,9 @@ bool get_bytes(napi_env env, napi_value v, const uint8_t** p, size_t* n) {
 
 napi_value wrap_result(napi_env env, uint8_t* data, size_t n) {
   napi_value ab, ta;
-  if (napi_create_external_arraybuffer(env, data, n, finalize_buf, nullptr, &ab) != napi_ok) {
+  int64_t adj = 0;
+  if (napi_create_external_arraybuffer(env, data, n, finalize_buf, (void*)(intptr_t)n, &ab) == napi_ok) napi_adjust_external_memory(env, (int64_t)n, &adj);
+  else {
     // some runtimes forbid external buffers: copy instead
     void* dst;
     napi_create_arraybuffer(env, n, &dst, &ab);

@@ -14,7 +14,7 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_f -- 
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_w -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-verify --no-extra > $o/pmc_w.log 2>&1 || { tail -5 $o/pmc_w.log; exit 1; }
 cp $(ls $o/pmc_f/*/*counter_collection.csv) $o/fetch_size_counter_collection.csv
 cp $(ls $o/pmc_w/*/*counter_collection.csv) $o/write_size_counter_collection.csv
-python3 tools/pmc_summary.py $o/fetch_size_counter_collection.csv $o/write_size_counter_collection.csv 3 > $o/pmc_traffic.json
+python3 tools/pmc_summary.py $o/fetch_size_counter_collection.csv $o/write_size_counter_collection.csv 3 100000000 > $o/pmc_traffic.json
 grep rs_scatter_ $o/pmc_traffic.json
 rm -rf $o/kt $o/pmc_f $o/pmc_w
 head -12 $o/kernel_summary.txt
