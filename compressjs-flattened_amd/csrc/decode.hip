@@ -396,7 +396,7 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         __syncthreads();
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
-      uint32_t v = CH_NONE;
+      uint32_t v = CH_NONE, mine = CH_NONE;
       for (int attempt = 0; attempt < 2; attempt++) {                      // (uniform)
       {
         // the length of the code that would start at bit i of the span: 1 + the number of lengths whose codes all lie below the 20
@@ -413,12 +413,14 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         }
         if (i < span + 64u) A[0][i] = (uint16_t)nx;
         if (tid < 64 && CH_T + (uint32_t)tid < span + 64u) A[0][CH_T + tid] = (uint16_t)CH_NONE;
+        mine = nx;
       }
       __syncthreads();
-      // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays
+      // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays.  A thread keeps its own entry in a register:
+      // one gather, one store and one barrier per round
 #pragma unroll
       for (int lv = 1; lv <= 5; lv++) {
-        if ((uint32_t)tid < span) { const uint32_t v = A[lv - 1][tid]; A[lv][tid] = (uint16_t)(v < span ? A[lv - 1][v] : v); }
+        if ((uint32_t)tid < span) { if (mine < span) mine = A[lv - 1][mine]; A[lv][tid] = (uint16_t)mine; }
         __syncthreads();
       }
       v = A[5][0];                                 // 32 codes
@@ -714,22 +716,39 @@ __global__ __launch_bounds__(256) void ib_pack_sentinel(const IbBlock* __restric
 }
 // splitters: slot j with j % SPL == 0, plus the start slot.  Walk until the next splitter.
 __device__ __forceinline__ bool is_split(uint32_t j, uint32_t start) { return (j % SPL) == 0 || j == start; }
+// The walks below are n dependent random 4-byte reads per block.  With every block's walkers spread over the chip each XCD's
+// 4 MiB L2 sees all blocks' vectors (3.6 MB each at level 9) and every step is a 64-byte fetch from memory: 2.4 + 3.2 ms per
+// 100 MB.  So (1) workgroup 8 j + x -- it runs on XCD x -- takes chunk x * ceil(T / 8) + j of the (block, 256 splitters) chunks:
+// an XCD works through a contiguous range of blocks; (2) the launches ask for WALK_LDS bytes of LDS they never touch, which
+// leaves five workgroups per CU: 40 K walkers per XCD, the splitters of about six blocks.  Measured (walk1 + walk2 per 100 MB):
+// blocks spread over the chip 5.57 ms; XCD ranges with 0 / 30 / 60 / 100 KB of LDS asked for 4.71 / 4.06 / 4.11 / 5.51 ms -- fewer
+// blocks in flight hit the L2 more often but leave too few walkers to hide what still misses.
+constexpr uint32_t WALK_T = 256, WALK_LDS = 30 * 1024;
+__host__ __device__ __forceinline__ uint32_t walk_chunks(uint32_t max_count) { return ((max_count + SPL - 1) / SPL + 1 + WALK_T - 1) / WALK_T; }
+__device__ __forceinline__ bool walk_item(uint32_t nblocks, uint32_t cpb, uint32_t& blk, uint32_t& sidx) {
+  const uint32_t T = nblocks * cpb, per = (T + 7u) >> 3;
+  const uint32_t t = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  if (t >= T) return false;
+  blk = t / cpb; sidx = (t - blk * cpb) * WALK_T + threadIdx.x;
+  return true;
+}
 constexpr uint32_t SPL_END = 0xFFFFFFFEu;   // the chain left the block (sentinel variant: the row of the implicit end marker)
-__global__ __launch_bounds__(256) void ib_walk1(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t spl_stride,
-                                                uint32_t* __restrict__ spl_next, uint32_t* __restrict__ spl_steps, int sentinel) {
-  const IbBlock b = blocks[blockIdx.y];
+__global__ __launch_bounds__(WALK_T) void ib_walk1(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t cpb,
+                                                   uint32_t spl_stride, uint32_t* __restrict__ spl_next, uint32_t* __restrict__ spl_steps, int sentinel) {
+  uint32_t blk, sidx;
+  if (!walk_item(nblocks, cpb, blk, sidx)) return;
+  const IbBlock b = blocks[blk];
   const uint32_t* d = dbuf + b.off;
-  const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;       // first slot visited by the loop (:1698-1700)
   const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;         // regular splitters + one slot for `start`
-  for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < nspl; sidx += gridDim.x * 256) {
-    uint32_t pos;
-    if (sidx == nspl - 1) { pos = start; if ((start % SPL) == 0) { spl_steps[(size_t)blockIdx.y * spl_stride + sidx] = 0; spl_next[(size_t)blockIdx.y * spl_stride + sidx] = start / SPL; continue; } }
-    else pos = sidx * SPL;
-    uint32_t steps = 0, cur = pos;
-    do { cur = d[cur] >> 8; steps++; } while (cur < b.count && !is_split(cur, start) && steps < b.count);
-    spl_steps[(size_t)blockIdx.y * spl_stride + sidx] = steps;
-    spl_next[(size_t)blockIdx.y * spl_stride + sidx] = cur >= b.count ? SPL_END : (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
-  }
+  if (sidx >= nspl) return;
+  const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;       // first slot visited by the loop (:1698-1700)
+  uint32_t pos;
+  if (sidx == nspl - 1) { pos = start; if ((start % SPL) == 0) { spl_steps[(size_t)blk * spl_stride + sidx] = 0; spl_next[(size_t)blk * spl_stride + sidx] = start / SPL; return; } }
+  else pos = sidx * SPL;
+  uint32_t steps = 0, cur = pos;
+  do { cur = d[cur] >> 8; steps++; } while (cur < b.count && !is_split(cur, start) && steps < b.count);
+  spl_steps[(size_t)blk * spl_stride + sidx] = steps;
+  spl_next[(size_t)blk * spl_stride + sidx] = cur >= b.count ? SPL_END : (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
 }
 // rank the splitter chain from `start`: spl_rank[s] = number of output positions before splitter s's segment.
 // One workgroup per block.  The chain is a list of <= 7034 nodes (a cycle through the start node for a cyclic BWT): the
@@ -806,24 +825,25 @@ __global__ __launch_bounds__(256) void ib_periodic_fill(const IbBlock* __restric
   for (uint32_t r = L + blockIdx.x * 256 + threadIdx.x; r < b.count; r += gridDim.x * 256) w[r] = w[r % L];
 }
 // second walk: write the pre-RLE1 byte sequence w[0..n) of each block (w[r] = byte of the (r+1)-th visited slot)
-__global__ __launch_bounds__(256) void ib_walk2(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t spl_stride,
-                                                const uint32_t* __restrict__ spl_rank, const uint32_t* __restrict__ spl_steps,
-                                                uint8_t* __restrict__ wbuf, int sentinel) {
-  const IbBlock b = blocks[blockIdx.y];
+__global__ __launch_bounds__(WALK_T) void ib_walk2(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t cpb,
+                                                   uint32_t spl_stride, const uint32_t* __restrict__ spl_rank, const uint32_t* __restrict__ spl_steps,
+                                                   uint8_t* __restrict__ wbuf, int sentinel) {
+  uint32_t blk, sidx;
+  if (!walk_item(nblocks, cpb, blk, sidx)) return;
+  const IbBlock b = blocks[blk];
   const uint32_t* d = dbuf + b.off;
   uint8_t* w = wbuf + b.off;
-  const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;
   const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;
-  for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < nspl; sidx += gridDim.x * 256) {
-    const uint32_t rank = spl_rank[(size_t)blockIdx.y * spl_stride + sidx], steps = spl_steps[(size_t)blockIdx.y * spl_stride + sidx];
-    if (rank == 0xFFFFFFFFu || steps == 0) continue;
-    uint32_t cur = sidx == nspl - 1 ? start : sidx * SPL;
-    // visiting order: position `rank` of the walk is slot `cur`; the loop outputs the byte of every visited slot (:1735-1736)
-    for (uint32_t q = 0; q < steps && rank + q < b.count; q++) {
-      const uint32_t e = d[cur];
-      w[sentinel ? b.count - 1 - (rank + q) : rank + q] = (uint8_t)(e & 0xFF);     // unbwtransform fills U from the end (BWTC:1161)
-      cur = e >> 8;
-    }
+  if (sidx >= nspl) return;
+  const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;
+  const uint32_t rank = spl_rank[(size_t)blk * spl_stride + sidx], steps = spl_steps[(size_t)blk * spl_stride + sidx];
+  if (rank == 0xFFFFFFFFu || steps == 0) return;
+  uint32_t cur = sidx == nspl - 1 ? start : sidx * SPL;
+  // visiting order: position `rank` of the walk is slot `cur`; the loop outputs the byte of every visited slot (:1735-1736)
+  for (uint32_t q = 0; q < steps && rank + q < b.count; q++) {
+    const uint32_t e = d[cur];
+    w[sentinel ? b.count - 1 - (rank + q) : rank + q] = (uint8_t)(e & 0xFF);     // unbwtransform fills U from the end (BWTC:1161)
+    cur = e >> 8;
   }
 }
 
@@ -835,88 +855,106 @@ __device__ __forceinline__ uint32_t fn_apply(uint32_t f, uint32_t c) { return (f
 __device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) {     // x -> then(first(x))
   return fn_apply(then, fn_apply(first, 0)) | (fn_apply(then, fn_apply(first, 1)) << 1);
 }
-// One workgroup per block, sequential 4096-byte tiles.  mode 0: count output bytes -> out_len; mode 1: write.
-__global__ __launch_bounds__(1024) void unrle1(const uint8_t* __restrict__ wbuf, IbBlock* __restrict__ blocks, uint8_t* __restrict__ out, int mode) {
-  __shared__ uint32_t sm[16];
-  __shared__ uint32_t fnarr[1024];
-  __shared__ uint32_t posarr[1024];
-  IbBlock b = blocks[blockIdx.x];
-  const uint8_t* w = wbuf + b.off;
-  const uint32_t n = b.count;
-  uint8_t* o = out + b.out_off;
-  // carried across tiles: start of the current stretch, c0 of the current stretch, output bytes so far
-  uint32_t cur_start = 0, cur_c0 = 0, out_base = 0;
-  for (uint32_t base = 0; base < n; base += 4096) {
-    const uint32_t p0 = base + threadIdx.x * 4;
-    uint8_t c[5]; c[0] = (p0 > 0 && p0 - 1 < n) ? w[p0 - 1] : 0;
+// One 4096-byte tile of a block by one 1024-thread workgroup.  Carried from the tiles in front: start of the current stretch,
+// c0 of the current stretch, output bytes so far; WRITE: the bytes go out, else they are only counted.
+struct RleCarry { uint32_t cur_start, cur_c0, out_base, pad; };
+template <bool WRITE>
+__device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint32_t n, uint32_t base, RleCarry& cy, uint8_t* __restrict__ o,
+                                            uint32_t* sm, uint32_t* fnarr, uint32_t* posarr) {
+  const uint32_t p0 = base + threadIdx.x * 4;
+  uint8_t c[5]; c[0] = (p0 > 0 && p0 - 1 < n) ? w[p0 - 1] : 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) c[j + 1] = p0 + j < n ? w[p0 + j] : 0;
-    // stretch boundaries inside my 4 positions
-    uint32_t bmask = 0, lastb = 0;
+  for (int j = 0; j < 4; j++) c[j + 1] = p0 + j < n ? w[p0 + j] : 0;
+  // stretch boundaries inside my 4 positions
+  uint32_t bmask = 0, lastb = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const uint32_t p = p0 + j; if (p < n && p > 0 && c[j + 1] != c[j]) { bmask |= 1u << j; lastb = p + 1; } }
-    // previous boundary before my first position: max-scan of (boundary position + 1), 0 = none in this tile
-    const uint32_t im = block_incl_max<1024>(lastb, sm);
-    posarr[threadIdx.x] = im;
+  for (int j = 0; j < 4; j++) { const uint32_t p = p0 + j; if (p < n && p > 0 && c[j + 1] != c[j]) { bmask |= 1u << j; lastb = p + 1; } }
+  // previous boundary before my first position: max-scan of (boundary position + 1), 0 = none in this tile
+  const uint32_t im = block_incl_max<1024>(lastb, sm);
+  posarr[threadIdx.x] = im;
+  __syncthreads();
+  const uint32_t exb = threadIdx.x ? posarr[threadIdx.x - 1] : 0u;
+  const uint32_t tile_last = posarr[1023];
+  __syncthreads();
+  // per-thread function = composition of the stretch functions of the boundaries in my 4 positions (in order);
+  // a boundary at p closes the stretch [prev_start, p) of length p - prev_start
+  uint32_t f = 2u;   // identity
+  {
+    uint32_t ps = exb ? exb - 1 : cy.cur_start;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if ((bmask >> j) & 1u) { const uint32_t p = p0 + j; f = fn_compose(f, stretch_fn(p - ps)); ps = p; }
+  }
+  // inclusive scan of function composition across threads (Hillis-Steele in LDS: 1024 entries)
+  fnarr[threadIdx.x] = f;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint32_t mine = fnarr[threadIdx.x];
+    const uint32_t other = threadIdx.x >= d ? fnarr[threadIdx.x - d] : 2u;
     __syncthreads();
-    const uint32_t exb = threadIdx.x ? posarr[threadIdx.x - 1] : 0u;
-    const uint32_t tile_last = posarr[1023];
+    fnarr[threadIdx.x] = fn_compose(other, mine);
     __syncthreads();
-    // per-thread function = composition of the stretch functions of the boundaries in my 4 positions (in order);
-    // a boundary at p closes the stretch [prev_start, p) of length p - prev_start
-    uint32_t f = 2u;   // identity
-    {
-      uint32_t ps = exb ? exb - 1 : cur_start;
+  }
+  const uint32_t fex = threadIdx.x ? fnarr[threadIdx.x - 1] : 2u;       // composition of all earlier threads' functions
+  const uint32_t fall = fnarr[1023];
+  __syncthreads();
+  // c0 of the stretch governing my first position
+  uint32_t c0 = fn_apply(fex, cy.cur_c0);
+  uint32_t ps = exb ? exb - 1 : cy.cur_start;
+  uint32_t cnt = 0, is_cnt = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) if ((bmask >> j) & 1u) { const uint32_t p = p0 + j; f = fn_compose(f, stretch_fn(p - ps)); ps = p; }
+  for (int j = 0; j < 4; j++) {
+    const uint32_t p = p0 + j;
+    if (p < n) {
+      if ((bmask >> j) & 1u) { c0 = fn_apply(stretch_fn(p - ps), c0); ps = p; }
+      const uint32_t q = ps + c0;                             // first literal of the stretch
+      const uint32_t rel = p >= q ? p - q : 0u;
+      const uint32_t count_byte = ((p == ps) & c0) | ((p >= q) & ((rel % 5u) == 4u));
+      is_cnt |= count_byte << j;
+      cnt += count_byte ? (uint32_t)c[j + 1] : 1u;
     }
-    // exclusive scan of function composition across threads (serial over 16 waves via LDS is fine: 1024 entries)
-    fnarr[threadIdx.x] = f;
-    __syncthreads();
-    // Hillis-Steele inclusive scan in LDS
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-      const uint32_t mine = fnarr[threadIdx.x];
-      const uint32_t other = threadIdx.x >= d ? fnarr[threadIdx.x - d] : 2u;
-      __syncthreads();
-      fnarr[threadIdx.x] = fn_compose(other, mine);
-      __syncthreads();
-    }
-    const uint32_t fex = threadIdx.x ? fnarr[threadIdx.x - 1] : 2u;       // composition of all earlier threads' functions
-    const uint32_t fall = fnarr[1023];
-    __syncthreads();
-    // c0 of the stretch governing my first position
-    uint32_t c0 = fn_apply(fex, cur_c0);
-    uint32_t ps = exb ? exb - 1 : cur_start;
-    uint32_t cnt = 0, is_cnt = 0;
+  }
+  uint32_t tot;
+  uint32_t off = cy.out_base + block_excl_sum<1024>(cnt, sm, tot);
+  if (WRITE) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const uint32_t p = p0 + j;
       if (p < n) {
-        if ((bmask >> j) & 1u) { c0 = fn_apply(stretch_fn(p - ps), c0); ps = p; }
-        const uint32_t q = ps + c0;                             // first literal of the stretch
-        const uint32_t rel = p >= q ? p - q : 0u;
-        const uint32_t count_byte = ((p == ps) & c0) | ((p >= q) & ((rel % 5u) == 4u));
-        is_cnt |= count_byte << j;
-        cnt += count_byte ? (uint32_t)c[j + 1] : 1u;
+        if ((is_cnt >> j) & 1u) { const uint32_t k = c[j + 1]; const uint8_t v = c[j]; for (uint32_t q = 0; q < k; q++) o[off + q] = v; off += k; }
+        else o[off++] = c[j + 1];
       }
     }
-    uint32_t tot;
-    uint32_t off = out_base + block_excl_sum<1024>(cnt, sm, tot);
-    if (mode == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t p = p0 + j;
-        if (p < n) {
-          if ((is_cnt >> j) & 1u) { const uint32_t k = c[j + 1]; const uint8_t v = c[j]; for (uint32_t q = 0; q < k; q++) o[off + q] = v; off += k; }
-          else o[off++] = c[j + 1];
-        }
-      }
-    }
-    out_base += tot;
-    // carry
-    if (tile_last) { cur_c0 = fn_apply(fall, cur_c0); cur_start = tile_last - 1; }
   }
-  if (mode == 0 && threadIdx.x == 0) blocks[blockIdx.x].out_len = out_base;
+  cy.out_base += tot;
+  if (tile_last) { cy.cur_c0 = fn_apply(fall, cy.cur_c0); cy.cur_start = tile_last - 1; }
+}
+// length pass: one workgroup per block, tiles front to back; leaves the state carried INTO every tile for the write pass
+constexpr uint32_t UR_TILE = 4096;
+__global__ __launch_bounds__(1024) void unrle1_count(const uint8_t* __restrict__ wbuf, IbBlock* __restrict__ blocks, RleCarry* __restrict__ carry, uint32_t tiles_per_block) {
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t fnarr[1024];
+  __shared__ uint32_t posarr[1024];
+  const IbBlock b = blocks[blockIdx.x];
+  const uint8_t* w = wbuf + b.off;
+  RleCarry cy{0u, 0u, 0u, 0u};
+  uint32_t t = 0;
+  for (uint32_t base = 0; base < b.count; base += UR_TILE, t++) {
+    if (threadIdx.x == 0 && t < tiles_per_block) carry[(size_t)blockIdx.x * tiles_per_block + t] = cy;
+    unrle1_tile<false>(w, b.count, base, cy, nullptr, sm, fnarr, posarr);
+  }
+  if (threadIdx.x == 0) blocks[blockIdx.x].out_len = cy.out_base;
+}
+// write pass: every tile of every block by itself
+__global__ __launch_bounds__(1024) void unrle1_write(const uint8_t* __restrict__ wbuf, const IbBlock* __restrict__ blocks, const RleCarry* __restrict__ carry,
+                                                     uint32_t tiles_per_block, uint8_t* __restrict__ out) {
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t fnarr[1024];
+  __shared__ uint32_t posarr[1024];
+  const IbBlock b = blocks[blockIdx.y];
+  const uint32_t base = blockIdx.x * UR_TILE;
+  if (base >= b.count) return;
+  RleCarry cy = carry[(size_t)blockIdx.y * tiles_per_block + blockIdx.x];
+  unrle1_tile<true>(wbuf + b.off, b.count, base, cy, out + b.out_off, sm, fnarr, posarr);
 }
 
 __global__ void ib_make_crc_ranges(const IbBlock* __restrict__ blocks, uint32_t nblocks, RleBlock* __restrict__ ranges, uint32_t* __restrict__ nb_dev) {
@@ -969,9 +1007,10 @@ static int ibwt_sentinel_slab(hipStream_t s, const uint8_t* d_T, uint32_t max_le
   uint32_t* sval = cur ? d_val1 : d_val0;
   uint32_t* d_dbuf = cur ? d_key0 : d_key1;
   hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_blocks, sval, d_dbuf);
-  hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_snext, d_ssteps, 1);
+  const uint32_t cpb = walk_chunks(max_len), wgrid = ((nb * cpb + 7u) >> 3) << 3;
+  hipLaunchKernelGGL(ib_walk1, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, d_blocks, nb, cpb, spl_stride, d_snext, d_ssteps, 1);
   hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
-  hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, d_blocks, spl_stride, d_srank, d_ssteps, d_out, 1);
+  hipLaunchKernelGGL(ib_walk2, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, d_blocks, nb, cpb, spl_stride, d_srank, d_ssteps, d_out, 1);
   std::vector<int32_t> errs(nb);
   if (hipGetLastError() != hipSuccess || hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
   cleanup();
@@ -1030,6 +1069,7 @@ struct DecShare {
   // chain part
   size_t c0 = 0, c1 = 0;              // chain blocks [c0, c1) were decoded here
   uint8_t* d_w = nullptr;             // pre-RLE1 bytes of those blocks, contiguous in chain order
+  RleCarry* d_carry = nullptr; uint32_t carry_tiles = 0;      // per chain block and 4096-byte tile: the RLE1 expansion state at the tile start
   std::vector<uint64_t> ebase;        // element offset of block c0+i inside d_w (size c1-c0+1)
   double ms_a = 0, ms_b = 0, ms_c = 0;
   char detail[96] = {0};            // error detail found by this share's worker thread (the detail text is per calling thread)
@@ -1214,6 +1254,8 @@ void dec_phase_b(DecJob* J, DecShare* S) {
   S->ebase.assign(nbk + 1, 0);
   for (size_t i = 0; i < nbk; i++) S->ebase[i + 1] = S->ebase[i] + J->chain[S->c0 + i].count;
   int rc = S->take((void**)&S->d_w, (size_t)S->ebase[nbk] + 64);
+  S->carry_tiles = (J->tt_stride + UR_TILE - 1) / UR_TILE;              // RLE1 state carried into every 4096-byte tile: written by phase B, read by phase C
+  if (!rc) rc = S->take((void**)&S->d_carry, sizeof(RleCarry) * (size_t)nbk * S->carry_tiles);
   if (rc) { S->rc = rc; return; }
   const uint32_t spl_stride = J->tt_stride / SPL + 4;
   for (size_t b0 = S->c0; b0 < S->c1 && !rc;) {
@@ -1244,11 +1286,12 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     uint32_t* sval = cur ? q.val1 : q.val0;
     uint32_t* d_dbuf = cur ? q.key0 : q.key1;                      // the buffer the sort is not sitting in
     hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, q.d_blocks, sval, d_dbuf);
-    hipLaunchKernelGGL(ib_walk1, dim3(8, nb), dim3(256), 0, s, d_dbuf, q.d_blocks, spl_stride, q.snext, q.ssteps, 0);
+    const uint32_t cpb = walk_chunks(J->tt_stride), wgrid = ((nb * cpb + 7u) >> 3) << 3;
+    hipLaunchKernelGGL(ib_walk1, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.snext, q.ssteps, 0);
     hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, q.d_blocks, nb, spl_stride, q.snext, q.ssteps, q.srank, q.d_err);
-    hipLaunchKernelGGL(ib_walk2, dim3(8, nb), dim3(256), 0, s, d_dbuf, q.d_blocks, spl_stride, q.srank, q.ssteps, d_wb, 0);
+    hipLaunchKernelGGL(ib_walk2, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.srank, q.ssteps, d_wb, 0);
     hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, q.d_blocks, q.d_err, d_wb);
-    hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, d_wb, q.d_blocks, (uint8_t*)nullptr, 0);
+    hipLaunchKernelGGL(unrle1_count, dim3(nb), dim3(1024), 0, s, d_wb, q.d_blocks, S->d_carry + (size_t)(b0 - S->c0) * S->carry_tiles, S->carry_tiles);
     std::vector<int32_t> errs(nb);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(J->chain.data() + b0, q.d_blocks, sizeof(IbBlock) * nb, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(errs.data(), q.d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = CJS_E_HIP; break; }
@@ -1290,7 +1333,7 @@ void dec_phase_c(DecJob* J, DecShare* S) {
     if (!rc) rc = S->take((void**)&d_crc, 4 * (size_t)nb);
     if (!rc && hipMemcpyAsync(d_blocks, blk.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
     if (rc) break;
-    hipLaunchKernelGGL(unrle1, dim3(nb), dim3(1024), 0, s, S->d_w + e0, d_blocks, d_out, 1);
+    hipLaunchKernelGGL(unrle1_write, dim3(S->carry_tiles, nb), dim3(1024), 0, s, S->d_w + e0, d_blocks, S->d_carry + (size_t)(b0 - S->c0) * S->carry_tiles, S->carry_tiles, d_out);
     hipLaunchKernelGGL(ib_make_crc_ranges, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, d_ranges, d_nb);
     rc = crc_ranges(s, d_out, d_ranges, d_nb, nb, need_segs, d_seg, d_crc);
     std::vector<uint32_t> crcs(nb);
