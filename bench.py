@@ -128,9 +128,7 @@ def host_abi_calls(pkg, n_devices):
         out, out_n = u8p(), ctypes.c_size_t(0)
         rc = fn(data.ctypes.data_as(u8p), data.size, *mid, ctypes.byref(out), ctypes.byref(out_n), ctypes.byref(opts))
         assert rc == 0, "%s failed: %d" % (fn.__name__, rc)
-        res = np.ctypeslib.as_array(out, shape=(out_n.value,)).copy()
-        L.cjs_free(out)
-        return res
+        return pkg._adopt(out, out_n.value)          # zero copy: cjs_free runs when the array is dropped (what the N-API addon does)
     return (lambda d, lvl: call(L.cjs_bzip2_compress, d, lvl), lambda d: call(L.cjs_bzip2_decompress, d, 0),
             lambda d, lvl: call(L.cjs_bwtc_compress, d, lvl), st)
 

@@ -332,9 +332,9 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
                                                  uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0) {
   __shared__ DecShared S;
-  __shared__ uint32_t scratch[6 * CH_ARR / 2 + CH_WORDS + 2];          // the prologue's selector values (4096 words), then the chain's arrays
+  __shared__ uint32_t scratch[7 * CH_ARR / 2 + CH_WORDS + 2];          // the prologue's selector values (4096 words), then the chain's arrays
   uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);
-  uint32_t* wbuf = scratch + 6 * CH_ARR / 2;
+  uint32_t* wbuf = scratch + 7 * CH_ARR / 2;
   __shared__ uint8_t selc[CH_T];
   __shared__ uint64_t s_pos;
   __shared__ uint32_t s_hdr[8];
@@ -375,63 +375,74 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   uint32_t ok_groups = 0;
   if (!herr) {
     uint64_t pos = data_bit, wbase = ~0ull;      // wbase: stream word at wbuf[0]
-    for (uint32_t k = 0; k < n_sel; k++) {
-      if ((k & (CH_T - 1)) == 0) {               // the next 256 selectors (written by lane 0 above: visible after the barrier)
+    uint32_t kb = 0xFFFFFFFFu;                   // first selector held in selc
+    for (uint32_t k = 0; k < n_sel;) {
+      if (kb == 0xFFFFFFFFu || k + 2 > kb + CH_T) {      // (uniform) the next 1024 selectors (written by lane 0 above: visible after the barrier)
         __syncthreads();
-        selc[tid] = k + tid < n_sel ? sel[k + tid] : 0;
+        kb = k;
+        selc[tid] = k + tid < n_sel ? sel[k + tid] : 0xFF;
         __syncthreads();
       }
-      const int g = selc[k & (CH_T - 1)];
-      if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
-      ok_groups = k + 1;
+      const int g = selc[k - kb];
+      // Three in five selectors of text repeat their predecessor: two groups under ONE table go in one step (100 codes of the same
+      // code: one more doubling round, the two ends by two threads).
+      const bool pair = k + 1 < n_sel && selc[k + 1 - kb] == g;
       // The span that is safe for any 50 codes (50 x the longest) is about three times what 50 codes of text take (~360 bits), and
-      // the rounds below are bound by LDS gathers per position: the first attempt works on CH_SHORT positions; a chain that leaves
-      // them (or meets a position where no code starts) is worked out again on the whole span.
+      // the rounds below are bound by LDS gathers per position: the first attempt works on CH_SHORT positions per group; a group
+      // whose chain leaves them (or meets a position where no code starts) is worked out again, alone, on its whole span.
       const uint32_t full_span = min(GROUP_SYMS * (uint32_t)S.maxlen[g], CH_SPAN);
-      uint32_t span = min(full_span, CH_SHORT);
-      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + full_span + 64) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
+      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + CH_SPAN + 64) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
         __syncthreads();
         wbase = pos >> 5;
         for (uint32_t i = tid; i < CH_WORDS + 2; i += CH_T) wbuf[i] = load_be32(in, n, wbase + i);
         __syncthreads();
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
-      uint32_t v = CH_NONE, mine = CH_NONE;
+      uint32_t e0 = CH_NONE, e1 = CH_NONE, span = 0;
       for (int attempt = 0; attempt < 2; attempt++) {                      // (uniform)
-      {
-        // the length of the code that would start at bit i of the span: 1 + the number of lengths whose codes all lie below the 20
-        // bits found there (no table lookup, no branch: at an arbitrary bit offset every twentieth position or so starts no short code)
-        const uint32_t i = (uint32_t)tid;
-        uint32_t nx = CH_NONE;
-        if (i < span) {
-          const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
-          const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-          uint32_t len = 1;
+        const uint32_t r = (attempt == 0 && pair) ? 2u : 1u;
+        span = attempt == 0 ? min(GROUP_SYMS * r * (uint32_t)S.maxlen[g], CH_SHORT * r) : full_span;
+        const int nlev = r == 2 ? 6 : 5;
+        uint32_t mine = CH_NONE;
+        {
+          // the length of the code that would start at bit i of the span: 1 + the number of lengths whose codes all lie below the 20
+          // bits found there (no table lookup, no branch: at an arbitrary bit offset every twentieth position or so starts no short code)
+          const uint32_t i = (uint32_t)tid;
+          if (i < span) {
+            const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
+            const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
+            uint32_t len = 1;
 #pragma unroll
-          for (int l = 1; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
-          if (x20 < S.limp[g][20]) nx = i + len;
+            for (int l = 1; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
+            if (x20 < S.limp[g][20]) mine = i + len;
+          }
+          if (i < span + 64u) A[0][i] = (uint16_t)mine;
+          if (tid < 64 && CH_T + (uint32_t)tid < span + 64u) A[0][CH_T + tid] = (uint16_t)CH_NONE;
         }
-        if (i < span + 64u) A[0][i] = (uint16_t)nx;
-        if (tid < 64 && CH_T + (uint32_t)tid < span + 64u) A[0][CH_T + tid] = (uint16_t)CH_NONE;
-        mine = nx;
-      }
-      __syncthreads();
-      // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays.  A thread keeps its own entry in a register:
-      // one gather, one store and one barrier per round
-#pragma unroll
-      for (int lv = 1; lv <= 5; lv++) {
-        if ((uint32_t)tid < span) { if (mine < span) mine = A[lv - 1][mine]; A[lv][tid] = (uint16_t)mine; }
         __syncthreads();
+        // next^2 .. next^32 (.. next^64): a value >= span has left the span (or is CH_NONE) and stays.  A thread keeps its own entry in
+        // a register: one gather, one store and one barrier per round
+        for (int lv = 1; lv <= nlev; lv++) {
+          if ((uint32_t)tid < span) { if (mine < span) mine = A[lv - 1][mine]; A[lv][tid] = (uint16_t)mine; }
+          __syncthreads();
+        }
+        // where 50 codes end (32 + 16 + 2) and, for a pair, where 100 end (64 + 32 + 4)
+        e0 = A[5][0];
+        if (e0 < span) e0 = A[4][e0];
+        if (e0 < span) e0 = A[1][e0];
+        e1 = CH_NONE;
+        if (r == 2) { e1 = A[6][0]; if (e1 < span) e1 = A[5][e1]; if (e1 < span) e1 = A[2][e1]; }
+        if (e0 <= span || span == full_span) break;
+        __syncthreads();                           // (everyone has read the short attempt's arrays)
       }
-      v = A[5][0];                                 // 32 codes
-      if (v < span) v = A[4][v];                   // + 16
-      if (v < span) v = A[1][v];                   // + 2
-      if (v <= span || span == full_span) break;
-      span = full_span;
-      __syncthreads();                             // (everyone has read the short attempt's arrays)
-      }
-      if (v > span) break;                         // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
-      pos += v;
+      if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
+      ok_groups = k + 1;
+      if (e0 > span) break;                        // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
+      if (e1 <= span) {                            // both groups of the pair
+        if (tid == 0) gstart[k + 1] = (uint32_t)(pos + e0 - data_bit);
+        ok_groups = k + 2;
+        pos += e1; k += 2;
+      } else { pos += e0; k += 1; }                // (the second group left the short span, or there was none: next step)
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
