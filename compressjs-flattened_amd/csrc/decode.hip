@@ -39,7 +39,11 @@ using namespace cjs;
 namespace cjs {
 
 constexpr uint64_t MAGIC_BLOCK = 0x314159265359ull, MAGIC_END = 0x177245385090ull;
-constexpr int SPL = 128;                  // one splitter every SPL slots of the LF vector
+// One splitter every SPL slots of the LF vector.  A walk ends where it lands on a splitter slot -- a 1-in-SPL chance per step --,
+// so the segments are geometric and the walk kernels last as long as the LONGEST of a block's segments, ~SPL x ln(n / SPL) steps
+// of dependent loads (1,100 at 128, 610 at 64): halving SPL halves them; the splitter chain of a block (14,064 nodes at level 9)
+// still fits the ranking kernel's LDS.
+constexpr int SPL = 64;
 
 struct Cand { uint64_t bit; uint32_t kind; uint32_t pad; };      // kind 0 = block, 1 = end of stream; pad = row of the block candidate in the decode buffer (set by the host)
 struct BlockOut {
@@ -477,10 +481,13 @@ __global__ __launch_bounds__(256) void bz_group_syms(const uint8_t* __restrict__
   uint64_t pos = data_bit + gstart_all[(size_t)row * (MAX_SELECTORS + 1) + k];
   uint16_t* syms = syms_all + (size_t)row * sym_stride;
   const int mx = maxlen[g];
+  // a 64-bit window on the stream: a code is at most 20 bits, so the cursor crosses at most one word per symbol (one load every
+  // four or five symbols of text instead of two per symbol)
+  uint64_t wdw = pos >> 5;
+  uint32_t w0 = load_be32(in, n, wdw), w1 = load_be32(in, n, wdw + 1);
   for (uint32_t j = 0; j < GROUP_SYMS; j++) {
     const uint64_t idx = (uint64_t)k * GROUP_SYMS + j;
-    const uint64_t dw = pos >> 5;
-    const uint32_t w0 = load_be32(in, n, dw), w1 = load_be32(in, n, dw + 1);
+    if ((pos >> 5) != wdw) { wdw++; w0 = w1; w1 = load_be32(in, n, wdw + 1); }
     const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (pos & 31)) >> 44);
     uint32_t e = fast[g][x20 >> 10], sym = 0, len = 0;
     if (e) { sym = e >> 5; len = e & 31u; }
@@ -762,11 +769,12 @@ __global__ __launch_bounds__(WALK_T) void ib_walk1(const uint32_t* __restrict__ 
   spl_next[(size_t)blk * spl_stride + sidx] = cur >= b.count ? SPL_END : (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
 }
 // rank the splitter chain from `start`: spl_rank[s] = number of output positions before splitter s's segment.
-// One workgroup per block.  The chain is a list of <= 7034 nodes (a cycle through the start node for a cyclic BWT): the
+// One workgroup per block.  The chain is a list of <= 14064 nodes (a cycle through the start node for a cyclic BWT): the
 // edge back into the first node is cut and the suffix sums of the segment lengths come from pointer jumping in LDS
-// (13 rounds) instead of 7000 dependent loads; rank = total - suffix sum.  If the total is not the block length the
+// (14 rounds) instead of 14000 dependent loads; rank = total - suffix sum.  If the total is not the block length the
 // permutation has a short cycle (periodic block) and lane 0 walks the chain the slow way, as the reference would.
-constexpr uint32_t IBR_MAX = 7104;       // >= 900000 / SPL + 2
+constexpr uint32_t IBR_MAX = 14080;      // >= 900000 / SPL + 2
+constexpr int IBR_PT = (IBR_MAX + 1023) / 1024;      // nodes per thread
 __global__ __launch_bounds__(1024) void ib_rank(const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t spl_stride, const uint32_t* __restrict__ spl_next,
                                                 const uint32_t* __restrict__ spl_steps, uint32_t* __restrict__ spl_rank, int32_t* __restrict__ err) {
   __shared__ uint32_t nxt[IBR_MAX], dst[IBR_MAX];
@@ -790,16 +798,16 @@ __global__ __launch_bounds__(1024) void ib_rank(const IbBlock* __restrict__ bloc
     }
     __syncthreads();
     for (uint32_t span = 1; span < nspl; span <<= 1) {
-      uint32_t nn[7], dd[7];
+      uint32_t nn[IBR_PT], dd[IBR_PT];
 #pragma unroll
-      for (int q = 0; q < 7; q++) {
+      for (int q = 0; q < IBR_PT; q++) {
         const uint32_t i = threadIdx.x + 1024u * q;
         nn[q] = SPL_END; dd[q] = 0;
         if (i < nspl) { const uint32_t n = nxt[i]; if (n != SPL_END) { nn[q] = nxt[n]; dd[q] = dst[n]; } else nn[q] = SPL_END; }
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 7; q++) {
+      for (int q = 0; q < IBR_PT; q++) {
         const uint32_t i = threadIdx.x + 1024u * q;
         if (i < nspl && nxt[i] != SPL_END) { dst[i] += dd[q]; nxt[i] = nn[q]; }
       }
@@ -866,20 +874,22 @@ __device__ __forceinline__ uint32_t fn_apply(uint32_t f, uint32_t c) { return (f
 __device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) {     // x -> then(first(x))
   return fn_apply(then, fn_apply(first, 0)) | (fn_apply(then, fn_apply(first, 1)) << 1);
 }
-// One 4096-byte tile of a block by one 1024-thread workgroup.  Carried from the tiles in front: start of the current stretch,
+// One tile (UR_TILE = 1024 threads x UR_BPT bytes) of a block by one workgroup.  Carried from the tiles in front: start of the current stretch,
 // c0 of the current stretch, output bytes so far; WRITE: the bytes go out, else they are only counted.
 struct RleCarry { uint32_t cur_start, cur_c0, out_base, pad; };
+constexpr int UR_BPT = 16;                    // bytes per thread: the ten-step function scan over the 1024 threads is most of a tile, whatever the bytes per thread (4 bytes: 1.05 ms per 100 MB for the length pass)
+constexpr uint32_t UR_TILE = 1024 * UR_BPT;
 template <bool WRITE>
 __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint32_t n, uint32_t base, RleCarry& cy, uint8_t* __restrict__ o,
                                             uint32_t* sm, uint32_t* fnarr, uint32_t* posarr) {
-  const uint32_t p0 = base + threadIdx.x * 4;
-  uint8_t c[5]; c[0] = (p0 > 0 && p0 - 1 < n) ? w[p0 - 1] : 0;
+  const uint32_t p0 = base + threadIdx.x * UR_BPT;
+  uint8_t c[UR_BPT + 1]; c[0] = (p0 > 0 && p0 - 1 < n) ? w[p0 - 1] : 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) c[j + 1] = p0 + j < n ? w[p0 + j] : 0;
-  // stretch boundaries inside my 4 positions
+  for (int j = 0; j < UR_BPT; j++) c[j + 1] = p0 + j < n ? w[p0 + j] : 0;
+  // stretch boundaries inside my positions
   uint32_t bmask = 0, lastb = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) { const uint32_t p = p0 + j; if (p < n && p > 0 && c[j + 1] != c[j]) { bmask |= 1u << j; lastb = p + 1; } }
+  for (int j = 0; j < UR_BPT; j++) { const uint32_t p = p0 + j; if (p < n && p > 0 && c[j + 1] != c[j]) { bmask |= 1u << j; lastb = p + 1; } }
   // previous boundary before my first position: max-scan of (boundary position + 1), 0 = none in this tile
   const uint32_t im = block_incl_max<1024>(lastb, sm);
   posarr[threadIdx.x] = im;
@@ -887,13 +897,13 @@ __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint3
   const uint32_t exb = threadIdx.x ? posarr[threadIdx.x - 1] : 0u;
   const uint32_t tile_last = posarr[1023];
   __syncthreads();
-  // per-thread function = composition of the stretch functions of the boundaries in my 4 positions (in order);
+  // per-thread function = composition of the stretch functions of the boundaries in my positions (in order);
   // a boundary at p closes the stretch [prev_start, p) of length p - prev_start
   uint32_t f = 2u;   // identity
   {
     uint32_t ps = exb ? exb - 1 : cy.cur_start;
 #pragma unroll
-    for (int j = 0; j < 4; j++) if ((bmask >> j) & 1u) { const uint32_t p = p0 + j; f = fn_compose(f, stretch_fn(p - ps)); ps = p; }
+    for (int j = 0; j < UR_BPT; j++) if ((bmask >> j) & 1u) { const uint32_t p = p0 + j; f = fn_compose(f, stretch_fn(p - ps)); ps = p; }
   }
   // inclusive scan of function composition across threads (Hillis-Steele in LDS: 1024 entries)
   fnarr[threadIdx.x] = f;
@@ -913,7 +923,7 @@ __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint3
   uint32_t ps = exb ? exb - 1 : cy.cur_start;
   uint32_t cnt = 0, is_cnt = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < UR_BPT; j++) {
     const uint32_t p = p0 + j;
     if (p < n) {
       if ((bmask >> j) & 1u) { c0 = fn_apply(stretch_fn(p - ps), c0); ps = p; }
@@ -928,7 +938,7 @@ __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint3
   uint32_t off = cy.out_base + block_excl_sum<1024>(cnt, sm, tot);
   if (WRITE) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < UR_BPT; j++) {
       const uint32_t p = p0 + j;
       if (p < n) {
         if ((is_cnt >> j) & 1u) { const uint32_t k = c[j + 1]; const uint8_t v = c[j]; for (uint32_t q = 0; q < k; q++) o[off + q] = v; off += k; }
@@ -940,7 +950,6 @@ __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint3
   if (tile_last) { cy.cur_c0 = fn_apply(fall, cy.cur_c0); cy.cur_start = tile_last - 1; }
 }
 // length pass: one workgroup per block, tiles front to back; leaves the state carried INTO every tile for the write pass
-constexpr uint32_t UR_TILE = 4096;
 __global__ __launch_bounds__(1024) void unrle1_count(const uint8_t* __restrict__ wbuf, IbBlock* __restrict__ blocks, RleCarry* __restrict__ carry, uint32_t tiles_per_block) {
   __shared__ uint32_t sm[16];
   __shared__ uint32_t fnarr[1024];
@@ -1080,7 +1089,7 @@ struct DecShare {
   // chain part
   size_t c0 = 0, c1 = 0;              // chain blocks [c0, c1) were decoded here
   uint8_t* d_w = nullptr;             // pre-RLE1 bytes of those blocks, contiguous in chain order
-  RleCarry* d_carry = nullptr; uint32_t carry_tiles = 0;      // per chain block and 4096-byte tile: the RLE1 expansion state at the tile start
+  RleCarry* d_carry = nullptr; uint32_t carry_tiles = 0;      // per chain block and UR_TILE-byte tile: the RLE1 expansion state at the tile start
   std::vector<uint64_t> ebase;        // element offset of block c0+i inside d_w (size c1-c0+1)
   double ms_a = 0, ms_b = 0, ms_c = 0;
   char detail[96] = {0};            // error detail found by this share's worker thread (the detail text is per calling thread)
@@ -1265,7 +1274,7 @@ void dec_phase_b(DecJob* J, DecShare* S) {
   S->ebase.assign(nbk + 1, 0);
   for (size_t i = 0; i < nbk; i++) S->ebase[i + 1] = S->ebase[i] + J->chain[S->c0 + i].count;
   int rc = S->take((void**)&S->d_w, (size_t)S->ebase[nbk] + 64);
-  S->carry_tiles = (J->tt_stride + UR_TILE - 1) / UR_TILE;              // RLE1 state carried into every 4096-byte tile: written by phase B, read by phase C
+  S->carry_tiles = (J->tt_stride + UR_TILE - 1) / UR_TILE;              // RLE1 state carried into every tile: written by phase B, read by phase C
   if (!rc) rc = S->take((void**)&S->d_carry, sizeof(RleCarry) * (size_t)nbk * S->carry_tiles);
   if (rc) { S->rc = rc; return; }
   const uint32_t spl_stride = J->tt_stride / SPL + 4;
