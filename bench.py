@@ -55,7 +55,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-PROFILE_DIR = "r03_v1"          # profiles/<dir>/pmc_traffic.json: PMC pass of this command (tools/gpu_round_profile.sh)
+PROFILE_DIR = "r03_final"          # profiles/<dir>/pmc_traffic.json: PMC pass of this command (tools/gpu_round_profile.sh)
 
 
 def log(*a):
