@@ -336,9 +336,10 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
                                                  uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0) {
   __shared__ DecShared S;
-  __shared__ uint32_t scratch[7 * CH_ARR / 2 + CH_WORDS + 2];          // the prologue's selector values (4096 words), then the chain's arrays
-  uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);
-  uint32_t* wbuf = scratch + 7 * CH_ARR / 2;
+  __shared__ uint32_t scratch[12 * CH_ARR / 2 + CH_WORDS + 2];         // the prologue's selector values (4096 words), then the chain's arrays
+  uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);                     // group k:     next^(2^lv), lv = 0 .. 5
+  uint16_t (*B)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch + 6 * CH_ARR / 2);    // group k + 1
+  uint32_t* wbuf = scratch + 12 * CH_ARR / 2;
   __shared__ uint8_t selc[CH_T];
   __shared__ uint64_t s_pos;
   __shared__ uint32_t s_hdr[8];
@@ -388,14 +389,19 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         __syncthreads();
       }
       const int g = selc[k - kb];
-      // Three in five selectors of text repeat their predecessor: two groups under ONE table go in one step (100 codes of the same
-      // code: one more doubling round, the two ends by two threads).
-      const bool pair = k + 1 < n_sel && selc[k + 1 - kb] == g;
+      // TWO groups per step.  The tables next^1 .. next^32 of a group do not depend on where the group starts, only on its code
+      // table and on the bit positions they cover.  So while the first CH_SHORT threads work on group k from its known start (A),
+      // ALL threads build the same tables for group k + 1 under ITS code table over the CH_SPAN positions from the earliest bit it
+      // can start at (50 x the shortest code of group k's table) (B) -- in the same rounds, behind the same barriers.  When the
+      // hops on A have found where group k ends, three more hops on B from that very position give the end of group k + 1.
       // The span that is safe for any 50 codes (50 x the longest) is about three times what 50 codes of text take (~360 bits), and
-      // the rounds below are bound by LDS gathers per position: the first attempt works on CH_SHORT positions per group; a group
-      // whose chain leaves them (or meets a position where no code starts) is worked out again, alone, on its whole span.
+      // the rounds are bound by LDS gathers per position: A's first attempt works on CH_SHORT positions; a chain that leaves them (or
+      // meets a position where no code starts) is worked out again, alone, on its whole span; a second group that leaves B's
+      // positions simply is the first group of the next step.
+      const int g1 = k + 1 < n_sel ? (int)selc[k + 1 - kb] : -1;
       const uint32_t full_span = min(GROUP_SYMS * (uint32_t)S.maxlen[g], CH_SPAN);
-      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + CH_SPAN + 64) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
+      const uint32_t base1 = GROUP_SYMS * (uint32_t)S.minlen[g];            // group k + 1 starts at or behind this offset
+      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + 2 * CH_SPAN + 128) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
         __syncthreads();
         wbase = pos >> 5;
         for (uint32_t i = tid; i < CH_WORDS + 2; i += CH_T) wbuf[i] = load_be32(in, n, wbase + i);
@@ -403,14 +409,14 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
       uint32_t e0 = CH_NONE, e1 = CH_NONE, span = 0;
+      bool ok0 = false;
       for (int attempt = 0; attempt < 2; attempt++) {                      // (uniform)
-        const uint32_t r = (attempt == 0 && pair) ? 2u : 1u;
-        span = attempt == 0 ? min(GROUP_SYMS * r * (uint32_t)S.maxlen[g], CH_SHORT * r) : full_span;
-        const int nlev = r == 2 ? 6 : 5;
-        uint32_t mine = CH_NONE;
+        const bool both = attempt == 0 && g1 >= 0;
+        span = attempt == 0 ? min(full_span, CH_SHORT) : full_span;
+        uint32_t mine = CH_NONE, mine1 = CH_NONE;
         {
-          // the length of the code that would start at bit i of the span: 1 + the number of lengths whose codes all lie below the 20
-          // bits found there (no table lookup, no branch: at an arbitrary bit offset every twentieth position or so starts no short code)
+          // the length of the code that would start at a bit: 1 + the number of lengths whose codes all lie below the 20 bits found
+          // there (no table lookup, no branch: at an arbitrary bit offset every twentieth position or so starts no short code)
           const uint32_t i = (uint32_t)tid;
           if (i < span) {
             const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
@@ -422,31 +428,50 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
           }
           if (i < span + 64u) A[0][i] = (uint16_t)mine;
           if (tid < 64 && CH_T + (uint32_t)tid < span + 64u) A[0][CH_T + tid] = (uint16_t)CH_NONE;
+          if (both) {                              // B: position tid of group k + 1's positions = bit base1 + tid of the step
+            const uint32_t o = o0 + base1 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
+            const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
+            uint32_t len = 1;
+#pragma unroll
+            for (int l = 1; l <= 19; l++) len += x20 >= S.limp[g1][l] ? 1u : 0u;
+            if (x20 < S.limp[g1][20]) mine1 = i + len;                          // (>= CH_SPAN: left B's positions)
+            B[0][i] = (uint16_t)mine1;
+          }
         }
         __syncthreads();
-        // next^2 .. next^32 (.. next^64): a value >= span has left the span (or is CH_NONE) and stays.  A thread keeps its own entry in
-        // a register: one gather, one store and one barrier per round
-        for (int lv = 1; lv <= nlev; lv++) {
+        // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays.  A thread keeps its own entries in registers:
+        // a gather, a store (two with B) and one barrier per round
+#pragma unroll
+        for (int lv = 1; lv <= 5; lv++) {
           if ((uint32_t)tid < span) { if (mine < span) mine = A[lv - 1][mine]; A[lv][tid] = (uint16_t)mine; }
+          if (both) { if (mine1 < CH_SPAN) mine1 = B[lv - 1][mine1]; B[lv][tid] = (uint16_t)mine1; }
           __syncthreads();
         }
-        // where 50 codes end (32 + 16 + 2) and, for a pair, where 100 end (64 + 32 + 4)
+        // where the 50 codes of group k end: 32 + 16 + 2
         e0 = A[5][0];
         if (e0 < span) e0 = A[4][e0];
         if (e0 < span) e0 = A[1][e0];
+        // A chain that has left its positions STAYS on the value it left with, and a value equal to the number of positions may be such
+        // a stop in the middle of the group: only a value below it is the end of 50 codes for sure -- except on the whole span, whose
+        // last position nothing but 50 codes of the longest length reach.
+        ok0 = e0 < span || (span == full_span && e0 == span);
         e1 = CH_NONE;
-        if (r == 2) { e1 = A[6][0]; if (e1 < span) e1 = A[5][e1]; if (e1 < span) e1 = A[2][e1]; }
-        if (e0 <= span || span == full_span) break;
+        if (both && ok0 && e0 >= base1 && e0 - base1 < CH_SPAN) {               // ... and from there the 50 codes of group k + 1, on B
+          e1 = B[5][e0 - base1];
+          if (e1 < CH_SPAN) e1 = B[4][e1];
+          if (e1 < CH_SPAN) e1 = B[1][e1];
+        }
+        if (ok0 || span == full_span) break;
         __syncthreads();                           // (everyone has read the short attempt's arrays)
       }
       if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
       ok_groups = k + 1;
-      if (e0 > span) break;                        // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
-      if (e1 <= span) {                            // both groups of the pair
+      if (!ok0) break;                             // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
+      if (e1 < CH_SPAN) {                          // both groups
         if (tid == 0) gstart[k + 1] = (uint32_t)(pos + e0 - data_bit);
         ok_groups = k + 2;
-        pos += e1; k += 2;
-      } else { pos += e0; k += 1; }                // (the second group left the short span, or there was none: next step)
+        pos += base1 + e1; k += 2;
+      } else { pos += e0; k += 1; }                // (the second group left B's positions, met an undecodable position, or there was none: next step)
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }

@@ -30,13 +30,23 @@ class Bits:
         return np.packbits(np.array(b, dtype=np.uint8))
 
 
-def make_stream(symbols, used=(97, 98), crc=0, orig=0, level=9, extra_selectors=0):
-    """one block: `symbols` (RUNA / RUNB / rank symbols 2.. ; the end-of-block symbol is appended) under two equal tables of
-    fixed-length codes; selectors all 0"""
+def make_stream(symbols, used=(97, 98), crc=0, orig=0, level=9, extra_selectors=0, lengths=None):
+    """one block: `symbols` (RUNA / RUNB / rank symbols 2.. ; the end-of-block symbol is appended) under two equal tables;
+    `lengths`: code length per symbol (canonical codes by (length, symbol)), default: all codes of one length; selectors all 0"""
     nsym_alpha = len(used) + 2
     eob = len(used) + 1
     syms = list(symbols) + [eob]
-    L = max(1, (nsym_alpha - 1).bit_length())
+    if lengths is None:
+        lengths = [max(1, (nsym_alpha - 1).bit_length())] * nsym_alpha
+    assert len(lengths) == nsym_alpha
+    codes, code, prev = {}, 0, min(lengths)
+    for ln in range(min(lengths), max(lengths) + 1):            # first[L + 1] = (first[L] + cnt[L]) << 1
+        code <<= (ln - prev)
+        prev = ln
+        for sy in range(nsym_alpha):
+            if lengths[sy] == ln:
+                codes[sy] = code
+                code += 1
     w = Bits()
     for ch in b"BZh%d" % level:
         w.put(ch, 8)
@@ -59,11 +69,18 @@ def make_stream(symbols, used=(97, 98), crc=0, orig=0, level=9, extra_selectors=
     for _ in range(nsel):
         w.put(0, 1)
     for _ in range(2):
-        w.put(L, 5)
-        for _ in range(nsym_alpha):
+        cur = lengths[0]
+        w.put(cur, 5)
+        for ln in lengths:                                       # '10' = one longer, '11' = one shorter, '0' = this symbol's length
+            while cur < ln:
+                w.put(2, 2)
+                cur += 1
+            while cur > ln:
+                w.put(3, 2)
+                cur -= 1
             w.put(0, 1)
     for s in syms:
-        w.put(s, L)                  # canonical codes of equal length are the symbol numbers
+        w.put(codes[s], lengths[s])
     w.put(0x177245385090, 48)
     w.put(crc, 32)                   # one block: the stream CRC is the block's
     return w.bytes()
@@ -120,6 +137,42 @@ def test_crafted_block(hip, oracle, name):
         assert rc_h == 0, (name, hip.last_error_detail())
     if name == "run19":
         assert out_h.size > 500000
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_groups_of_every_length_in_bits(hip, oracle, seed):
+    # The decoder finds the end of a group of 50 codes by pointer doubling over a window of bit positions that is shorter than the
+    # longest possible group, working a group out again when its chain leaves the window, and speculates on the group behind it.
+    # Mixes of a 1-bit and a 20-bit code give groups of 50 .. 1000 bits whose code boundaries fall on every window edge.
+    rng = np.random.RandomState(1000 + seed)
+    p_long = (0.02, 0.2, 0.45, 0.5, 0.55, 0.8, 0.98, 1.0)[seed % 8]
+    n = (60, 260, 700, 1500)[seed % 4]
+    symbols = [3 if x < p_long else 2 for x in rng.random_sample(n)]
+    if seed % 3 == 0:                                            # a few short zero-rank runs in between (20-bit codes too)
+        for at in rng.randint(0, n, 5):
+            symbols[at] = RUNA
+    rc_h, rc_o, out_h, out_o = decode_both(hip, oracle, symbols, used=(65, 66, 67), lengths=[20, 20, 1, 20, 20])
+    assert rc_h == rc_o == 0, (seed, rc_h, rc_o, hip.last_error_detail())
+    assert out_h.size == out_o.size and np.array_equal(out_h, out_o), seed
+
+
+def test_group_ends_on_a_window_edge(hip, oracle):
+    # code boundaries exactly on bit 512 of a group (the first attempt's window) in the middle of the group and as its very end,
+    # and the same for the group behind it (whose window starts 50 bits into the step: bit 1074)
+    L, S = 3, 2                                                  # 20-bit and 1-bit rank symbols
+    mid = [L] * 25 + [S] * 12 + [L] * 5 + [S] * 8                # 512 bits after 37 codes, 50 codes in all
+    end = [L] * 24 + [S] * 18 + [L] * 0 + [S] * 8                # 498 + ... (made exact below)
+    end = [L] * 24 + [S] * 26                                    # 480 + 26 = 506: a little below the edge
+    exact = [L] * 25 + [S] * 12 + [S] * 13                       # 512 + 13 = 525 bits
+    at_edge = [L] * 24 + [S] * 24 + [L] * 1 + [S] * 1            # 480 + 24 = 504, + 20 = 524 ...
+    edge_end = [S] * 28 + [L] * 22                               # 28 + 440 = 468
+    full = [L] * 50                                              # 1000 bits: the whole span
+    for name, groups in (("mid", [mid, mid, mid]), ("short-long", [end, full, exact, full, mid]), ("full", [full, full, full]),
+                         ("mixed", [at_edge, edge_end, mid, exact, end, full, mid])):
+        symbols = [x for g in groups for x in g]
+        rc_h, rc_o, out_h, out_o = decode_both(hip, oracle, symbols, used=(65, 66, 67), lengths=[20, 20, 1, 20, 20])
+        assert rc_h == rc_o == 0, (name, rc_h, rc_o, hip.last_error_detail())
+        assert np.array_equal(out_h, out_o), name
 
 
 def test_missing_end_of_block_is_a_data_error(hip, oracle):
