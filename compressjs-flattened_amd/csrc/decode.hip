@@ -765,7 +765,8 @@ __device__ __forceinline__ bool is_split(uint32_t j, uint32_t start) { return (j
 // an XCD works through a contiguous range of blocks; (2) the launches ask for WALK_LDS bytes of LDS they never touch, which
 // leaves five workgroups per CU: 40 K walkers per XCD, the splitters of about six blocks.  Measured (walk1 + walk2 per 100 MB):
 // blocks spread over the chip 5.57 ms; XCD ranges with 0 / 30 / 60 / 100 KB of LDS asked for 4.71 / 4.06 / 4.11 / 5.51 ms -- fewer
-// blocks in flight hit the L2 more often but leave too few walkers to hide what still misses.
+// blocks in flight hit the L2 more often but leave too few walkers to hide what still misses (with a splitter every 64 slots:
+// 0 / 16 / 30 / 45 / 60 KB 3.53 / 3.51 / 2.90 / 2.91 / 3.32 ms).
 constexpr uint32_t WALK_T = 256, WALK_LDS = 30 * 1024;
 __host__ __device__ __forceinline__ uint32_t walk_chunks(uint32_t max_count) { return ((max_count + SPL - 1) / SPL + 1 + WALK_T - 1) / WALK_T; }
 __device__ __forceinline__ bool walk_item(uint32_t nblocks, uint32_t cpb, uint32_t& blk, uint32_t& sidx) {
@@ -1189,13 +1190,13 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   // Block decode in three stages (Huffman chain per block -> (rank, offset) ops; move-to-front of all 256-op tiles in parallel;
   // emit), over BATCHES of rows: a row of scratch is sized for a whole block of the file's largest level (~7 x tt_stride bytes),
   // whatever the candidate turns out to hold, so a file of very many tiny member streams (or one stuffed with block magics)
-  // must not get a row per candidate at once.  One batch (the usual case: <= ~1300 level-9 rows in 8 GiB) keeps its decoded
+  // must not get a row per candidate at once.  One batch (the usual case: <= ~2000 level-9 rows in 16 GiB: a 2^30-byte stream has 1,194) keeps its decoded
   // rows where they are; with several batches each batch's decoded bytes are packed into a buffer of their exact size and
   // the scratch rows are used again.
   BlockOut* d_bo = nullptr;
   const uint32_t dsz = J->tt_stride;
   const uint32_t ops_stride = (dsz + 256u + 255u) & ~255u, tiles_per_row = ops_stride / MT_TILE;
-  static const uint64_t budget = getenv("CJS_DEC_ROW_BYTES") ? strtoull(getenv("CJS_DEC_ROW_BYTES"), nullptr, 10) : (8ull << 30);      // (tests shrink it)
+  static const uint64_t budget = getenv("CJS_DEC_ROW_BYTES") ? strtoull(getenv("CJS_DEC_ROW_BYTES"), nullptr, 10) : (16ull << 30);      // (tests shrink it)
   const uint32_t sym_stride = dsz + 4096u;                              // symbols in front of the end of block: each emits a byte (but for forgotten runs), so <= dsz
   const uint32_t group_tiles = (std::min<uint32_t>(MAX_SELECTORS, sym_stride / GROUP_SYMS + 1u) + 255u) / 256u;
   const uint64_t per_row = (uint64_t)dsz + 6ull * ops_stride + 256 + 4 + sizeof(RowTab) + MAX_SELECTORS + 4ull * (MAX_SELECTORS + 1) + 2ull * sym_stride;
