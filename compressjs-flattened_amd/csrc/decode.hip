@@ -931,18 +931,33 @@ __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint3
 #pragma unroll
     for (int j = 0; j < UR_BPT; j++) if ((bmask >> j) & 1u) { const uint32_t p = p0 + j; f = fn_compose(f, stretch_fn(p - ps)); ps = p; }
   }
-  // inclusive scan of function composition across threads (Hillis-Steele in LDS: 1024 entries)
-  fnarr[threadIdx.x] = f;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    const uint32_t mine = fnarr[threadIdx.x];
-    const uint32_t other = threadIdx.x >= d ? fnarr[threadIdx.x - d] : 2u;
+  // exclusive scan of function composition across the 1024 threads: shuffles inside the waves, the sixteen wave totals through LDS
+  // (two barriers; as a ten-step Hillis-Steele scan in LDS, twenty barriers, this was most of a tile)
+  uint32_t incl = f;
+  {
+    const int lane = lane_id(), wv = wave_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t other = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl = fn_compose(other, incl);           // (the earlier threads' function first)
+    }
+    if (lane == 63) fnarr[wv] = incl;
     __syncthreads();
-    fnarr[threadIdx.x] = fn_compose(other, mine);
+    if (wv == 0) {
+      uint32_t t = lane < 16 ? fnarr[lane] : 2u;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t other = (uint32_t)__shfl_up((int)t, d, 64);
+        if (lane >= d) t = fn_compose(other, t);
+      }
+      if (lane < 16) fnarr[16 + lane] = t;                     // inclusive over the waves
+    }
     __syncthreads();
   }
-  const uint32_t fex = threadIdx.x ? fnarr[threadIdx.x - 1] : 2u;       // composition of all earlier threads' functions
-  const uint32_t fall = fnarr[1023];
+  const uint32_t wprefix = wave_id() ? fnarr[16 + wave_id() - 1] : 2u;          // all earlier waves
+  uint32_t fex = (uint32_t)__shfl_up((int)incl, 1, 64);
+  fex = lane_id() ? fn_compose(wprefix, fex) : wprefix;                          // composition of all earlier threads' functions
+  const uint32_t fall = fnarr[16 + 15];
   __syncthreads();
   // c0 of the stretch governing my first position
   uint32_t c0 = fn_apply(fex, cy.cur_c0);
