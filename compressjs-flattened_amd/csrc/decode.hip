@@ -332,6 +332,18 @@ constexpr uint32_t GROUP_SYMS = 50;
 constexpr uint32_t MAX_SELECTORS = 32768;
 
 
+// Position of the bit behind the code that starts at position i with the 20 bits x20 under table g (CH_NONE: no code starts there).
+// A code of <= 10 bits is one gather in the 10-bit direct table; a longer one (a few percent of ARBITRARY bit offsets, but most waves
+// hold one) counts the lengths 11 .. 19 whose left-justified codes all lie below x20.
+__device__ __forceinline__ uint32_t chain_next(const DecShared& S, int g, uint32_t x20, uint32_t i) {
+  const uint32_t e = S.fast[g][x20 >> 10];
+  if (e) return i + (e & 31u);
+  uint32_t len = 11;
+#pragma unroll
+  for (int l = 11; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
+  return x20 < S.limp[g][20] ? i + len : CH_NONE;
+}
+
 __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
                                                  uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0) {
@@ -415,26 +427,19 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         span = attempt == 0 ? min(full_span, CH_SHORT) : full_span;
         uint32_t mine = CH_NONE, mine1 = CH_NONE;
         {
-          // the length of the code that would start at a bit: 1 + the number of lengths whose codes all lie below the 20 bits found
-          // there (no table lookup, no branch: at an arbitrary bit offset every twentieth position or so starts no short code)
+          // next^1: the bit behind the code that would start at each position (chain_next)
           const uint32_t i = (uint32_t)tid;
           if (i < span) {
             const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
             const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-            uint32_t len = 1;
-#pragma unroll
-            for (int l = 1; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
-            if (x20 < S.limp[g][20]) mine = i + len;
+            mine = chain_next(S, g, x20, i);
           }
           if (i < span + 64u) A[0][i] = (uint16_t)mine;
           if (tid < 64 && CH_T + (uint32_t)tid < span + 64u) A[0][CH_T + tid] = (uint16_t)CH_NONE;
           if (both) {                              // B: position tid of group k + 1's positions = bit base1 + tid of the step
             const uint32_t o = o0 + base1 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
             const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-            uint32_t len = 1;
-#pragma unroll
-            for (int l = 1; l <= 19; l++) len += x20 >= S.limp[g1][l] ? 1u : 0u;
-            if (x20 < S.limp[g1][20]) mine1 = i + len;                          // (>= CH_SPAN: left B's positions)
+            mine1 = chain_next(S, g1, x20, i);                                  // (>= CH_SPAN: left B's positions)
             B[0][i] = (uint16_t)mine1;
           }
         }
