@@ -287,7 +287,12 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   return err;
 }
 
-__device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
+__device__ uint64_t g_dec_clk[9];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
+#ifdef XV_CLK
+#define XCLK(...) __VA_ARGS__
+#else
+#define XCLK(...)
+#endif
 #define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
 // ---------------------------------------------------------------- 2b. block decode in stages
 // The Huffman chain of a block looks serial -- the table changes every 50 symbols, so there is no self-synchronisation to exploit
@@ -322,12 +327,16 @@ struct RowTab {                    // per candidate row, in global memory betwee
   unsigned long long eob_key;      // min over end-of-block symbols of (symbol index << 32 | bit behind the code - data_bit); ~0 = none
   unsigned long long err_key;      // min over undecodable codes of (symbol index << 32); ~0 = none
 };
+#ifdef XV_T512
+constexpr uint32_t CH_T = 512;
+#else
 constexpr uint32_t CH_T = 1024;                 // threads of bz_chain: one per bit position of the span
+#endif
 constexpr uint32_t CH_SPAN = 1024;              // bit positions of a group's span (50 codes of <= 20 bits)
 constexpr uint32_t CH_ARR = CH_SPAN + 64;
+constexpr uint32_t CH_NONE = CH_ARR - 1;         // next[] of a position where no code of the table starts (an entry of its own, like the positions behind a span)
 constexpr uint32_t CH_SHORT = 512;              // positions of a step's first attempt
 constexpr uint32_t CH_WORDS = 2048;             // 32-bit words of the stream kept in LDS (65536 bits: ~180 groups of text)
-constexpr uint32_t CH_NONE = 0xFFFFu;           // next[] of a position where no code of the table starts
 constexpr uint32_t GROUP_SYMS = 50;
 constexpr uint32_t MAX_SELECTORS = 32768;
 
@@ -335,24 +344,41 @@ constexpr uint32_t MAX_SELECTORS = 32768;
 // Position of the bit behind the code that starts at position i with the 20 bits x20 under table g (CH_NONE: no code starts there).
 // A code of <= 10 bits is one gather in the 10-bit direct table; a longer one (a few percent of ARBITRARY bit offsets, but most waves
 // hold one) counts the lengths 11 .. 19 whose left-justified codes all lie below x20.
-__device__ __forceinline__ uint32_t chain_next(const DecShared& S, int g, uint32_t x20, uint32_t i) {
-  const uint32_t e = S.fast[g][x20 >> 10];
-  if (e) return i + (e & 31u);
+// The bit behind the code that starts at position i with the 20 bits x20 under table g (CH_NONE: no code starts there).  e = the
+// table's entry of the 12-bit direct table (bz_chain): the length of a code of <= 12 bits, CH_NOCODE, or 0: a longer code (a fraction
+// of a percent of ARBITRARY bit offsets), whose length is 13 + the number of lengths 13 .. 19 whose left-justified codes all lie below x20.
+constexpr uint32_t CH_NOCODE = 0xFF;
+__device__ __forceinline__ uint32_t chain_next(const DecShared& S, int g, uint32_t e, uint32_t x20, uint32_t i) {
+  if (e) return e == CH_NOCODE ? CH_NONE : i + e;
+  uint32_t len = 13;
+#pragma unroll
+  for (int l = 13; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
+  return x20 < S.limp[g][20] ? i + len : CH_NONE;
+}
+
+__device__ __forceinline__ uint32_t chain_next10(const DecShared& S, int g, uint32_t x20, uint32_t i) {
   uint32_t len = 11;
 #pragma unroll
   for (int l = 11; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
   return x20 < S.limp[g][20] ? i + len : CH_NONE;
 }
-
+// bz_chain's tables: level lv of table t (uint16_t[6][CH_ARR]) by byte offset
+__device__ __forceinline__ uint32_t ch_ld(uint16_t (*t)[CH_ARR], int lv, uint32_t off) { return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(t[lv]) + off); }
+__device__ __forceinline__ void ch_st(uint16_t (*t)[CH_ARR], int lv, uint32_t i, uint32_t v) { t[lv][i] = (uint16_t)v; }
+#ifdef XV_L12
+#define CHAIN_NEXT(g, x20, i) chain_next(S, g, len12[g][(x20) >> 8], x20, i)
+#else
+#define CHAIN_NEXT(g, x20, i) (S.fast[g][(x20) >> 10] ? (i) + (S.fast[g][(x20) >> 10] & 31u) : chain_next10(S, g, x20, i))
+#endif
 __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
-                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0) {
+                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0, uint32_t xb_w, uint32_t xb_num, uint32_t xb_short) {
   __shared__ DecShared S;
   __shared__ uint32_t scratch[12 * CH_ARR / 2 + CH_WORDS + 2];         // the prologue's selector values (4096 words), then the chain's arrays
   uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);                     // group k:     next^(2^lv), lv = 0 .. 5
   uint16_t (*B)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch + 6 * CH_ARR / 2);    // group k + 1
   uint32_t* wbuf = scratch + 12 * CH_ARR / 2;
-  __shared__ uint8_t selc[CH_T];
+  __shared__ uint8_t len12[6][4096];            // code length by the next 12 bits (chain_next)
   __shared__ uint64_t s_pos;
   __shared__ uint32_t s_hdr[8];
   const uint32_t c = blockIdx.x;
@@ -389,18 +415,39 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   for (uint32_t i = tid; i < 6 * 260; i += CH_T) (&T.bysym[0][0])[i] = (&S.bysym[0][0])[i];
   if (tid < 8) { T.minlen[tid] = S.minlen[tid]; T.maxlen[tid] = S.maxlen[tid]; }
   for (int i = tid; i < 256; i += CH_T) l0_all[(size_t)row * 256 + i] = S.sym_to_byte[i];
+  // 12-bit direct length tables.  The length rule is 1 + #{L in 1..19 : x20 >= limp[L]}, and a limit of a length <= 12 has its low 8
+  // bits clear: the 12 bits x decide those; with all 12 below x the code is longer (or there is none) and the entry is 0.
+#ifdef XV_L12
+  if (!herr) {
+    for (uint32_t e = tid; e < group_count * 4096u; e += CH_T) {
+      const uint32_t t = e >> 12, x = e & 4095u;
+      uint32_t c = 0;
+#pragma unroll
+      for (int l = 1; l <= 12; l++) c += x >= (S.limp[t][l] >> 8) ? 1u : 0u;
+      len12[t][x] = (uint8_t)(c == 12 ? 0u : (x << 8) < S.limp[t][20] ? c + 1 : CH_NOCODE);
+    }
+  }
+#endif
+  // (the positions behind the last a thread writes, once for every level)
+  if (tid < 64) for (int lv = 0; lv < 6; lv++) { A[lv][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); B[lv][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); }
+  __syncthreads();
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t ok_groups = 0;
+  XCLK(uint64_t x_steps = 0, x_two = 0, x_retry = 0, x_c1 = 0, x_c2 = 0, x_c3 = 0, x_c4 = 0; const uint64_t xT0 = clock64();)
   if (!herr) {
     uint64_t pos = data_bit, wbase = ~0ull;      // wbase: stream word at wbuf[0]
-    uint32_t kb = 0xFFFFFFFFu;                   // first selector held in selc
+    // Nothing the step's first instructions need comes from memory: the tables' shortest / longest lengths sit in two registers (5 bits
+    // each), and lane j of every wave holds the selectors kb + j, kb + 64 + j (and, on its way, kb + 128 + j) -- written by wave 0 above,
+    // visible after the barrier.
+    uint32_t minp = 0, maxp = 0;
+    for (int t = 0; t < 6; t++) { minp |= ((uint32_t)S.minlen[t] & 31u) << (5 * t); maxp |= ((uint32_t)S.maxlen[t] & 31u) << (5 * t); }
+    minp = (uint32_t)__builtin_amdgcn_readfirstlane((int)minp); maxp = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxp);
+    uint32_t kb = 0, lp = 0;
+    uint32_t slo = (uint32_t)lane < n_sel ? sel[lane] : 0xFFu, shi = 64u + lane < n_sel ? sel[64 + lane] : 0xFFu, snx = 128u + lane < n_sel ? sel[128 + lane] : 0xFFu;
     for (uint32_t k = 0; k < n_sel;) {
-      if (kb == 0xFFFFFFFFu || k + 2 > kb + CH_T) {      // (uniform) the next 1024 selectors (written by lane 0 above: visible after the barrier)
-        __syncthreads();
-        kb = k;
-        selc[tid] = k + tid < n_sel ? sel[k + tid] : 0xFF;
-        __syncthreads();
-      }
-      const int g = selc[k - kb];
+      if (k >= kb + 64) { kb += 64; slo = shi; shi = snx; snx = kb + 128 + lane < n_sel ? sel[kb + 128 + lane] : 0xFFu; }      // (uniform; k moves by <= 2)
+      const uint32_t kj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k - kb));
+      const int g = __builtin_amdgcn_readlane((int)slo, (int)kj);
       // TWO groups per step.  The tables next^1 .. next^32 of a group do not depend on where the group starts, only on its code
       // table and on the bit positions they cover.  So while the first CH_SHORT threads work on group k from its known start (A),
       // ALL threads build the same tables for group k + 1 under ITS code table over the CH_SPAN positions from the earliest bit it
@@ -410,9 +457,9 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       // the rounds are bound by LDS gathers per position: A's first attempt works on CH_SHORT positions; a chain that leaves them (or
       // meets a position where no code starts) is worked out again, alone, on its whole span; a second group that leaves B's
       // positions simply is the first group of the next step.
-      const int g1 = k + 1 < n_sel ? (int)selc[k + 1 - kb] : -1;
-      const uint32_t full_span = min(GROUP_SYMS * (uint32_t)S.maxlen[g], CH_SPAN);
-      const uint32_t base1 = GROUP_SYMS * (uint32_t)S.minlen[g];            // group k + 1 starts at or behind this offset
+      const int g1 = k + 1 < n_sel ? (kj < 63 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 1) & 63)) : __builtin_amdgcn_readlane((int)shi, 0)) : -1;
+      const uint32_t full_span = min(GROUP_SYMS * ((maxp >> (5 * g)) & 31u), CH_SPAN);
+      const uint32_t base1 = GROUP_SYMS * ((minp >> (5 * g)) & 31u);        // group k + 1 starts at or behind this offset
       if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + 2 * CH_SPAN + 128) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
         __syncthreads();
         wbase = pos >> 5;
@@ -420,66 +467,80 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         __syncthreads();
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
+      XCLK(x_steps++; const uint64_t xt0 = clock64();)
       uint32_t e0 = CH_NONE, e1 = CH_NONE, span = 0;
       bool ok0 = false;
+      const uint32_t bstart = min(max(base1, lp * xb_num >> 3), CH_SPAN);
       for (int attempt = 0; attempt < 2; attempt++) {                      // (uniform)
         const bool both = attempt == 0 && g1 >= 0;
-        span = attempt == 0 ? min(full_span, CH_SHORT) : full_span;
-        uint32_t mine = CH_NONE, mine1 = CH_NONE;
-        {
-          // next^1: the bit behind the code that would start at each position (chain_next)
-          const uint32_t i = (uint32_t)tid;
+        span = attempt == 0 ? min(full_span, xb_short) : full_span;
+        // Tables hold BYTE OFFSETS (2 x position) into a level's array, and every position from the span's end up to the next multiple
+        // of 64 (>= 64 of them: a code is at most 20 bits) maps to itself, as does CH_GONE: a chain that has left the span, or met a
+        // position where no code starts, stays where it is without a compare -- a round is one gather and one store per table.
+        const uint32_t wa = min((span + 127u) >> 6, CH_T / 64), wb = both ? min((xb_w + 127u) >> 6, CH_T / 64) : 0u;      // waves at work on A / B
+        const uint32_t i = (uint32_t)tid;
+        uint32_t ma = 2 * i, mb = 2 * i;
+        if (wv < wa) {
           if (i < span) {
             const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
             const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-            mine = chain_next(S, g, x20, i);
+            ma = 2 * CHAIN_NEXT(g, x20, i);
           }
-          if (i < span + 64u) A[0][i] = (uint16_t)mine;
-          if (tid < 64 && CH_T + (uint32_t)tid < span + 64u) A[0][CH_T + tid] = (uint16_t)CH_NONE;
-          if (both) {                              // B: position tid of group k + 1's positions = bit base1 + tid of the step
-            const uint32_t o = o0 + base1 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
+          ch_st(A, 0, i, ma);
+        }
+        if (wv < wb) {                             // B: position tid of group k + 1's positions = bit bstart + tid of the step
+          if (i < xb_w) {
+            const uint32_t o = o0 + bstart + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
             const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-            mine1 = chain_next(S, g1, x20, i);                                  // (>= CH_SPAN: left B's positions)
-            B[0][i] = (uint16_t)mine1;
+            mb = 2 * CHAIN_NEXT(g1, x20, i);
           }
+          ch_st(B, 0, i, mb);
         }
         __syncthreads();
-        // next^2 .. next^32: a value >= span has left the span (or is CH_NONE) and stays.  A thread keeps its own entries in registers:
-        // a gather, a store (two with B) and one barrier per round
+        XCLK(const uint64_t xt1 = clock64(); if (attempt == 0) x_c1 += xt1 - xt0; else x_retry++;)
+        // next^2 .. next^32.  Where the 50 codes of group k end: 2 + 16 + 32, each hop as soon as its table stands -- the first two travel
+        // beside the following round's gathers, one is left behind the last barrier.
+        uint32_t hop = 0;
 #pragma unroll
         for (int lv = 1; lv <= 5; lv++) {
-          if ((uint32_t)tid < span) { if (mine < span) mine = A[lv - 1][mine]; A[lv][tid] = (uint16_t)mine; }
-          if (both) { if (mine1 < CH_SPAN) mine1 = B[lv - 1][mine1]; B[lv][tid] = (uint16_t)mine1; }
+          if (wv < wa) ma = ch_ld(A, lv - 1, ma);
+          if (wv < wb) mb = ch_ld(B, lv - 1, mb);
+          if (wv < wa) ch_st(A, lv, i, ma);
+          if (wv < wb) ch_st(B, lv, i, mb);
           __syncthreads();
+          if (lv == 1) hop = ch_ld(A, 1, 0);
+          if (lv == 4) hop = ch_ld(A, 4, hop);
         }
-        // where the 50 codes of group k end: 32 + 16 + 2
-        e0 = A[5][0];
-        if (e0 < span) e0 = A[4][e0];
-        if (e0 < span) e0 = A[1][e0];
+        XCLK(const uint64_t xt2 = clock64(); x_c2 += xt2 - xt1;)
+        e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch_ld(A, 5, hop)) >> 1;
         // A chain that has left its positions STAYS on the value it left with, and a value equal to the number of positions may be such
         // a stop in the middle of the group: only a value below it is the end of 50 codes for sure -- except on the whole span, whose
         // last position nothing but 50 codes of the longest length reach.
         ok0 = e0 < span || (span == full_span && e0 == span);
         e1 = CH_NONE;
-        if (both && ok0 && e0 >= base1 && e0 - base1 < CH_SPAN) {               // ... and from there the 50 codes of group k + 1, on B
-          e1 = B[5][e0 - base1];
-          if (e1 < CH_SPAN) e1 = B[4][e1];
-          if (e1 < CH_SPAN) e1 = B[1][e1];
+        if (both && ok0 && e0 >= bstart && e0 - bstart < xb_w) {               // ... and from there the 50 codes of group k + 1, on B
+          e1 = ch_ld(B, 1, ch_ld(B, 4, ch_ld(B, 5, 2 * (e0 - bstart))));
+          e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e1) >> 1;
         }
+        XCLK(x_c3 += clock64() - xt2;)
         if (ok0 || span == full_span) break;
         __syncthreads();                           // (everyone has read the short attempt's arrays)
       }
       if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
       ok_groups = k + 1;
       if (!ok0) break;                             // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
-      if (e1 < CH_SPAN) {                          // both groups
+      XCLK(x_c4 += clock64() - xt0;)
+      if (e1 < xb_w) {                             // both groups
+        XCLK(x_two++;)
         if (tid == 0) gstart[k + 1] = (uint32_t)(pos + e0 - data_bit);
         ok_groups = k + 2;
-        pos += base1 + e1; k += 2;
-      } else { pos += e0; k += 1; }                // (the second group left B's positions, met an undecodable position, or there was none: next step)
+        lp = bstart + e1 - e0;
+        pos += bstart + e1; k += 2;
+      } else { lp = e0; pos += e0; k += 1; }                // (the second group left B's positions, met an undecodable position, or there was none: next step)
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
+  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[1] = x_c1; g_dec_clk[2] = x_c2; g_dec_clk[3] = x_c3; g_dec_clk[4] = x_c4; g_dec_clk[8] = clock64() - xT0; })
   if (tid == 0) {
     T.sym_total = s_hdr[1]; T.group_count = group_count; T.n_sel = n_sel; T.err = (uint32_t)herr; T.data_bit = data_bit; T.crc = s_hdr[4]; T.orig = s_hdr[5];
     T.ngroups_ok = ok_groups; T.pad = 0; T.eob_key = ~0ull; T.err_key = ~0ull;
@@ -1244,7 +1305,8 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     uint32_t c1 = c0, rows = 0, r0 = 0;
     while (c1 < ncand && (S->cands[c1].kind != 0 || rows < nr)) { if (S->cands[c1].kind == 0) { if (!rows) r0 = S->cands[c1].pad; rows++; } c1++; }
     const uint32_t nc = c1 - c0;
-    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0);
+    { static const uint32_t xw = getenv("CJS_X_BW") ? (uint32_t)atoi(getenv("CJS_X_BW")) : 448u, xn = getenv("CJS_X_BNUM") ? (uint32_t)atoi(getenv("CJS_X_BNUM")) : 0u, xs = getenv("CJS_X_SHORT") ? (uint32_t)atoi(getenv("CJS_X_SHORT")) : 448u;
+    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0, xw, xn, xs); }
     if (rows) hipLaunchKernelGGL(bz_group_syms, dim3(group_tiles, rows), dim3(256), 0, s, S->d_in, S->up_hi, d_tabs, d_sel, d_gstart, d_syms, sym_stride, 0u);
     hipLaunchKernelGGL(bz_sym_ops, dim3(nc), dim3(1024), 0, s, d_tabs, d_cand + c0, nc, d_syms, sym_stride, dsz, d_ops, d_opoff, ops_stride, d_nops, d_bo + c0, r0, S->up_hi * 8);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data() + c0, d_bo + c0, sizeof(BlockOut) * nc, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1284,8 +1346,9 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops); S->drop(d_tabs); S->drop(d_sel); S->drop(d_gstart); S->drop(d_syms);
   if (!single) { S->drop(d_ttb); S->drop(d_gdst); }
   if (getenv("CJS_DEBUG")) {
-    uint64_t clk[8];
+    uint64_t clk[9];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
+      fprintf(stderr, "[cjs dec] X steps %llu two %llu retry %llu | cycles next1 %llu rounds %llu hops %llu step %llu total %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
       fprintf(stderr, "[cjs dec] candidate 0: header + tables %.1f us, group chain %.1f us for %llu groups\n", clk[5] / 100.0, clk[6] / 100.0, (unsigned long long)clk[7]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
