@@ -287,7 +287,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   return err;
 }
 
-__device__ uint64_t g_dec_clk[9];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
+__device__ uint64_t g_dec_clk[10];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
 #ifdef XV_CLK
 #define XCLK(...) __VA_ARGS__
 #else
@@ -327,57 +327,132 @@ struct RowTab {                    // per candidate row, in global memory betwee
   unsigned long long eob_key;      // min over end-of-block symbols of (symbol index << 32 | bit behind the code - data_bit); ~0 = none
   unsigned long long err_key;      // min over undecodable codes of (symbol index << 32); ~0 = none
 };
-#ifdef XV_T512
-constexpr uint32_t CH_T = 512;
-#else
-constexpr uint32_t CH_T = 1024;                 // threads of bz_chain: one per bit position of the span
-#endif
+constexpr uint32_t CH_T = 512;                  // threads of bz_chain
 constexpr uint32_t CH_SPAN = 1024;              // bit positions of a group's span (50 codes of <= 20 bits)
 constexpr uint32_t CH_ARR = CH_SPAN + 64;
 constexpr uint32_t CH_NONE = CH_ARR - 1;         // next[] of a position where no code of the table starts (an entry of its own, like the positions behind a span)
-constexpr uint32_t CH_SHORT = 512;              // positions of a step's first attempt
+constexpr uint32_t CH_WIN = CH_T - 64;          // positions of a table in a step's first attempt: one per thread, the last 64 map to themselves
+constexpr uint32_t CH_ARR2 = CH_T + 64;         // the later groups' tables: CH_WIN positions, and 64 + 64 that map to themselves
+constexpr uint32_t CH_NONE2 = CH_ARR2 - 1;
 constexpr uint32_t CH_WORDS = 2048;             // 32-bit words of the stream kept in LDS (65536 bits: ~180 groups of text)
 constexpr uint32_t GROUP_SYMS = 50;
 constexpr uint32_t MAX_SELECTORS = 32768;
 
 
-// Position of the bit behind the code that starts at position i with the 20 bits x20 under table g (CH_NONE: no code starts there).
-// A code of <= 10 bits is one gather in the 10-bit direct table; a longer one (a few percent of ARBITRARY bit offsets, but most waves
-// hold one) counts the lengths 11 .. 19 whose left-justified codes all lie below x20.
-// The bit behind the code that starts at position i with the 20 bits x20 under table g (CH_NONE: no code starts there).  e = the
-// table's entry of the 12-bit direct table (bz_chain): the length of a code of <= 12 bits, CH_NOCODE, or 0: a longer code (a fraction
-// of a percent of ARBITRARY bit offsets), whose length is 13 + the number of lengths 13 .. 19 whose left-justified codes all lie below x20.
+// bz_chain's tables: level lv of table t (uint16_t[6][CH_ARR]) by byte offset
+template <uint32_t N> __device__ __forceinline__ uint32_t ch_ld(uint16_t (*t)[N], int lv, uint32_t off) { return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(t[lv]) + off); }
+template <uint32_t N> __device__ __forceinline__ void ch_st(uint16_t (*t)[N], int lv, uint32_t i, uint32_t v) { t[lv][i] = (uint16_t)v; }
+// The 20 bits at bit o of the window
+__device__ __forceinline__ uint32_t chain_bits(const uint32_t* wbuf, uint32_t o) {
+  const uint32_t w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
+  return (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
+}
+// The position behind the code that starts at position i with the 20 bits x20 under table g (CH_NONE: no code starts there).  e is the
+// entry of the 12-bit direct table: the length of a code of <= 12 bits, CH_NOCODE, or 0 for a longer code, whose length is 13 + the
+// number of lengths 13 .. 19 whose left-justified codes all lie below x20 (well under a percent of ARBITRARY bit offsets: one wave in
+// four holds one; with a 10-bit table nearly every wave did and paid the compares).
 constexpr uint32_t CH_NOCODE = 0xFF;
-__device__ __forceinline__ uint32_t chain_next(const DecShared& S, int g, uint32_t e, uint32_t x20, uint32_t i) {
-  if (e) return e == CH_NOCODE ? CH_NONE : i + e;
+__device__ __forceinline__ uint32_t chain_next(const DecShared& S, int g, uint32_t e, uint32_t x20, uint32_t i, uint32_t none) {
+  if (e) return e == CH_NOCODE ? none : i + e;
   uint32_t len = 13;
 #pragma unroll
   for (int l = 13; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
-  return x20 < S.limp[g][20] ? i + len : CH_NONE;
+  return x20 < S.limp[g][20] ? i + len : none;
+}
+// One step's tables for NT groups (k on A from its known start, k + 1 on B from bit bstart, k + 2 on C from bit cstart): next^1, then
+// five rounds of doubling.  Tables hold BYTE OFFSETS (2 x position) into a level's array, and every position behind a table's last
+// (>= 64 of them: a code is at most 20 bits) maps to itself, as does CH_NONE: a chain that has left its positions, or met one where no
+// code starts, stays where it is without a compare -- a round is one gather and one store per table, all threads on all tables, no
+// branch (the kernel's scalar unit serves every wave's branches and address arithmetic: with one thread per position and table, and
+// a branch around each, those instructions outnumbered the vector ones three to one and set the pace).  e0 / e1 / e2: where the groups
+// end, in positions of A / B / C (every lane the same value; CH_NONE or beyond a table's positions: not known from this step).  Group k's
+// 50 codes are 2 + 16 + 32: the first two hops as soon as their table stands, beside the following round's gathers.
+template <int NT>
+__device__ __forceinline__ void chain_tables(const DecShared& S, const uint8_t (*len12)[4096], const uint32_t* wbuf, uint16_t (*A)[CH_ARR], uint16_t (*B)[CH_ARR2], uint16_t (*C)[CH_ARR2],
+                                                 uint32_t i, uint32_t o0, int g, int g1, int g2, uint32_t span, bool whole, uint32_t bstart, uint32_t cstart,
+                                                 uint32_t& e0, uint32_t& e1, uint32_t& e2) {
+  // (the tables' loads side by side: two LDS latencies for the three, not six)
+  const uint32_t xa = chain_bits(wbuf, o0 + i), xb = NT >= 2 ? chain_bits(wbuf, o0 + bstart + i) : 0u, xc = NT >= 3 ? chain_bits(wbuf, o0 + cstart + i) : 0u;
+  const uint32_t ea = len12[g][xa >> 8], eb = NT >= 2 ? len12[g1][xb >> 8] : 1u, ec = NT >= 3 ? len12[g2][xc >> 8] : 1u;
+  uint32_t ma = chain_next(S, g, ea, xa, i, CH_NONE), mb = 0, mc = 0;
+  ma = 2 * (i < span ? ma : i);
+  if (NT >= 2) { mb = chain_next(S, g1, eb, xb, i, CH_NONE2); mb = 2 * (i < CH_WIN ? mb : i); }
+  if (NT >= 3) { mc = chain_next(S, g2, ec, xc, i, CH_NONE2); mc = 2 * (i < CH_WIN ? mc : i); }
+  ch_st(A, 0, i, ma);
+  if (NT >= 2) ch_st(B, 0, i, mb);
+  if (NT >= 3) ch_st(C, 0, i, mc);
+  __syncthreads();
+  uint32_t hop = 0;
+#pragma unroll
+  for (int lv = 1; lv <= 4; lv++) {
+    ma = ch_ld(A, lv - 1, ma);
+    if (NT >= 2) mb = ch_ld(B, lv - 1, mb);
+    if (NT >= 3) mc = ch_ld(C, lv - 1, mc);
+    ch_st(A, lv, i, ma);
+    if (NT >= 2) ch_st(B, lv, i, mb);
+    if (NT >= 3) ch_st(C, lv, i, mc);
+    __syncthreads();
+    if (lv == 1) hop = ch_ld(A, 1, 0);
+    if (lv == 4) hop = ch_ld(A, 4, hop);
+  }
+  // The last round: A's next^32 (one hop is left for it), but B's and C's next^50 = next^2 . next^16 . next^32 outright: two more gathers
+  // here (every position at once) instead of two more hops each behind the barrier (one after the other).
+  ma = ch_ld(A, 4, ma);
+  if (NT >= 2) mb = ch_ld(B, 4, mb);
+  if (NT >= 3) mc = ch_ld(C, 4, mc);
+  ch_st(A, 5, i, ma);
+  if (NT >= 2) mb = ch_ld(B, 4, mb);
+  if (NT >= 3) mc = ch_ld(C, 4, mc);
+  if (NT >= 2) mb = ch_ld(B, 1, mb);
+  if (NT >= 3) mc = ch_ld(C, 1, mc);
+  if (NT >= 2) ch_st(B, 5, i, mb);
+  if (NT >= 3) ch_st(C, 5, i, mc);
+  __syncthreads();
+  // Where the groups end.  A chain that has left its positions STAYS on the value it left with, and a value equal to the number of
+  // positions may be such a stop in the middle of the group: only a value below it is the end of 50 codes for sure -- except on the
+  // whole span, whose last position nothing but 50 codes of the longest length reach.  A group that starts outside its table's
+  // positions is looked up at CH_NONE, which maps to itself.
+  e0 = ch_ld(A, 5, hop) >> 1;
+  e1 = e2 = CH_NONE2;
+  if (NT >= 2) {
+    const bool in_b = (e0 < span || (whole && e0 == span)) && e0 >= bstart && e0 - bstart < CH_WIN;
+    e1 = ch_ld(B, 5, 2 * (in_b ? e0 - bstart : CH_NONE2)) >> 1;
+  }
+  if (NT >= 3) {
+    const uint32_t s2 = bstart + e1;
+    const bool in_c = e1 < CH_WIN && s2 >= cstart && s2 - cstart < CH_WIN;
+    e2 = ch_ld(C, 5, 2 * (in_c ? s2 - cstart : CH_NONE2)) >> 1;
+  }
+}
+// The same for group k alone on its whole span (two positions per thread)
+__device__ __forceinline__ uint32_t chain_table_full(const DecShared& S, const uint8_t (*len12)[4096], const uint32_t* wbuf, uint16_t (*A)[CH_ARR], uint32_t i, uint32_t o0, int g, uint32_t span) {
+  const uint32_t j = i + CH_T;
+  const uint32_t x0 = chain_bits(wbuf, o0 + i), x1 = chain_bits(wbuf, o0 + j);
+  uint32_t m0 = chain_next(S, g, len12[g][x0 >> 8], x0, i, CH_NONE), m1 = chain_next(S, g, len12[g][x1 >> 8], x1, j, CH_NONE);
+  m0 = 2 * (i < span ? m0 : i); m1 = 2 * (j < span ? m1 : j);
+  ch_st(A, 0, i, m0); ch_st(A, 0, j, m1);
+  __syncthreads();
+  uint32_t hop = 0;
+#pragma unroll
+  for (int lv = 1; lv <= 5; lv++) {
+    m0 = ch_ld(A, lv - 1, m0); m1 = ch_ld(A, lv - 1, m1);
+    ch_st(A, lv, i, m0); ch_st(A, lv, j, m1);
+    __syncthreads();
+    if (lv == 1) hop = ch_ld(A, 1, 0);
+    if (lv == 4) hop = ch_ld(A, 4, hop);
+  }
+  return hop;
 }
 
-__device__ __forceinline__ uint32_t chain_next10(const DecShared& S, int g, uint32_t x20, uint32_t i) {
-  uint32_t len = 11;
-#pragma unroll
-  for (int l = 11; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
-  return x20 < S.limp[g][20] ? i + len : CH_NONE;
-}
-// bz_chain's tables: level lv of table t (uint16_t[6][CH_ARR]) by byte offset
-__device__ __forceinline__ uint32_t ch_ld(uint16_t (*t)[CH_ARR], int lv, uint32_t off) { return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(t[lv]) + off); }
-__device__ __forceinline__ void ch_st(uint16_t (*t)[CH_ARR], int lv, uint32_t i, uint32_t v) { t[lv][i] = (uint16_t)v; }
-#ifdef XV_L12
-#define CHAIN_NEXT(g, x20, i) chain_next(S, g, len12[g][(x20) >> 8], x20, i)
-#else
-#define CHAIN_NEXT(g, x20, i) (S.fast[g][(x20) >> 10] ? (i) + (S.fast[g][(x20) >> 10] & 31u) : chain_next10(S, g, x20, i))
-#endif
 __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
-                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0, uint32_t xb_w, uint32_t xb_num, uint32_t xb_short) {
+                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0, uint32_t xb_num, uint32_t xc_num) {
   __shared__ DecShared S;
-  __shared__ uint32_t scratch[12 * CH_ARR / 2 + CH_WORDS + 2];         // the prologue's selector values (4096 words), then the chain's arrays
+  __shared__ uint32_t scratch[6 * CH_ARR / 2 + 12 * CH_ARR2 / 2 + CH_WORDS + 2];         // the prologue's selector values (4096 words), then the chain's arrays
   uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);                     // group k:     next^(2^lv), lv = 0 .. 5
-  uint16_t (*B)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch + 6 * CH_ARR / 2);    // group k + 1
-  uint32_t* wbuf = scratch + 12 * CH_ARR / 2;
+  uint16_t (*B)[CH_ARR2] = reinterpret_cast<uint16_t (*)[CH_ARR2]>(scratch + 6 * CH_ARR / 2);                    // group k + 1
+  uint16_t (*C)[CH_ARR2] = reinterpret_cast<uint16_t (*)[CH_ARR2]>(scratch + 6 * CH_ARR / 2 + 6 * CH_ARR2 / 2);   // group k + 2
+  uint32_t* wbuf = scratch + 6 * CH_ARR / 2 + 12 * CH_ARR2 / 2;
   __shared__ uint8_t len12[6][4096];            // code length by the next 12 bits (chain_next)
   __shared__ uint64_t s_pos;
   __shared__ uint32_t s_hdr[8];
@@ -417,7 +492,6 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   for (int i = tid; i < 256; i += CH_T) l0_all[(size_t)row * 256 + i] = S.sym_to_byte[i];
   // 12-bit direct length tables.  The length rule is 1 + #{L in 1..19 : x20 >= limp[L]}, and a limit of a length <= 12 has its low 8
   // bits clear: the 12 bits x decide those; with all 12 below x the code is longer (or there is none) and the entry is 0.
-#ifdef XV_L12
   if (!herr) {
     for (uint32_t e = tid; e < group_count * 4096u; e += CH_T) {
       const uint32_t t = e >> 12, x = e & 4095u;
@@ -427,13 +501,11 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       len12[t][x] = (uint8_t)(c == 12 ? 0u : (x << 8) < S.limp[t][20] ? c + 1 : CH_NOCODE);
     }
   }
-#endif
   // (the positions behind the last a thread writes, once for every level)
-  if (tid < 64) for (int lv = 0; lv < 6; lv++) { A[lv][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); B[lv][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); }
+  if (tid < 64) for (int lv = 0; lv < 6; lv++) { A[lv][CH_SPAN + tid] = (uint16_t)(2 * (CH_SPAN + tid)); B[lv][CH_T + tid] = C[lv][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); }
   __syncthreads();
-  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t ok_groups = 0;
-  XCLK(uint64_t x_steps = 0, x_two = 0, x_retry = 0, x_c1 = 0, x_c2 = 0, x_c3 = 0, x_c4 = 0; const uint64_t xT0 = clock64();)
+  XCLK(uint64_t x_steps = 0, x_two = 0, x_three = 0, x_retry = 0, x_c1 = 0, x_c2 = 0, x_c3 = 0, x_c4 = 0; const uint64_t xT0 = clock64();)
   if (!herr) {
     uint64_t pos = data_bit, wbase = ~0ull;      // wbase: stream word at wbuf[0]
     // Nothing the step's first instructions need comes from memory: the tables' shortest / longest lengths sit in two registers (5 bits
@@ -448,18 +520,20 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       if (k >= kb + 64) { kb += 64; slo = shi; shi = snx; snx = kb + 128 + lane < n_sel ? sel[kb + 128 + lane] : 0xFFu; }      // (uniform; k moves by <= 2)
       const uint32_t kj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k - kb));
       const int g = __builtin_amdgcn_readlane((int)slo, (int)kj);
-      // TWO groups per step.  The tables next^1 .. next^32 of a group do not depend on where the group starts, only on its code
-      // table and on the bit positions they cover.  So while the first CH_SHORT threads work on group k from its known start (A),
-      // ALL threads build the same tables for group k + 1 under ITS code table over the CH_SPAN positions from the earliest bit it
-      // can start at (50 x the shortest code of group k's table) (B) -- in the same rounds, behind the same barriers.  When the
-      // hops on A have found where group k ends, three more hops on B from that very position give the end of group k + 1.
-      // The span that is safe for any 50 codes (50 x the longest) is about three times what 50 codes of text take (~360 bits), and
-      // the rounds are bound by LDS gathers per position: A's first attempt works on CH_SHORT positions; a chain that leaves them (or
-      // meets a position where no code starts) is worked out again, alone, on its whole span; a second group that leaves B's
-      // positions simply is the first group of the next step.
+      // Up to THREE groups per step.  The tables next^1 .. next^32 of a group do not depend on where the group starts, only on its
+      // code table and on the bit positions they cover.  So beside group k's tables from its known start (A) the same threads build
+      // those of group k + 1 under ITS code table over CH_WIN positions from the earliest bit it can start at (50 x the shortest code
+      // of group k's table, or a share of the last group's length if that is more) (B), and of group k + 2 likewise (C) -- in the same
+      // rounds, behind the same barriers.  When the hops on A have found where group k ends, three hops on B from that very position
+      // give the end of group k + 1, and three on C the end of group k + 2.  The span that is safe for any 50 codes (50 x the
+      // longest) is about five times what 50 codes of text take (~210 bits): the first attempt works on CH_WIN positions; a group k
+      // that leaves them (or meets a position where no code starts) is worked out again, alone, on its whole span; a later group
+      // that leaves its table's positions, or starts in front of them, simply is the first group of the next step.
       const int g1 = k + 1 < n_sel ? (kj < 63 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 1) & 63)) : __builtin_amdgcn_readlane((int)shi, 0)) : -1;
+      const int g2 = k + 2 < n_sel ? (kj < 62 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 2) & 63)) : __builtin_amdgcn_readlane((int)shi, (int)((kj + 2) & 63))) : -1;
       const uint32_t full_span = min(GROUP_SYMS * ((maxp >> (5 * g)) & 31u), CH_SPAN);
       const uint32_t base1 = GROUP_SYMS * ((minp >> (5 * g)) & 31u);        // group k + 1 starts at or behind this offset
+      const uint32_t base2 = base1 + (g1 >= 0 ? GROUP_SYMS * ((minp >> (5 * g1)) & 31u) : 0u);      // ... and group k + 2 at or behind this one
       if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + 2 * CH_SPAN + 128) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
         __syncthreads();
         wbase = pos >> 5;
@@ -467,70 +541,32 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         __syncthreads();
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
-      XCLK(x_steps++; const uint64_t xt0 = clock64();)
-      uint32_t e0 = CH_NONE, e1 = CH_NONE, span = 0;
-      bool ok0 = false;
+      XCLK(x_steps++;)
+      const uint32_t i = (uint32_t)tid;
       const uint32_t bstart = min(max(base1, lp * xb_num >> 3), CH_SPAN);
-      for (int attempt = 0; attempt < 2; attempt++) {                      // (uniform)
-        const bool both = attempt == 0 && g1 >= 0;
-        span = attempt == 0 ? min(full_span, xb_short) : full_span;
-        // Tables hold BYTE OFFSETS (2 x position) into a level's array, and every position from the span's end up to the next multiple
-        // of 64 (>= 64 of them: a code is at most 20 bits) maps to itself, as does CH_GONE: a chain that has left the span, or met a
-        // position where no code starts, stays where it is without a compare -- a round is one gather and one store per table.
-        const uint32_t wa = min((span + 127u) >> 6, CH_T / 64), wb = both ? min((xb_w + 127u) >> 6, CH_T / 64) : 0u;      // waves at work on A / B
-        const uint32_t i = (uint32_t)tid;
-        uint32_t ma = 2 * i, mb = 2 * i;
-        if (wv < wa) {
-          if (i < span) {
-            const uint32_t o = o0 + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
-            const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-            ma = 2 * CHAIN_NEXT(g, x20, i);
-          }
-          ch_st(A, 0, i, ma);
-        }
-        if (wv < wb) {                             // B: position tid of group k + 1's positions = bit bstart + tid of the step
-          if (i < xb_w) {
-            const uint32_t o = o0 + bstart + i, w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
-            const uint32_t x20 = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (o & 31)) >> 44);
-            mb = 2 * CHAIN_NEXT(g1, x20, i);
-          }
-          ch_st(B, 0, i, mb);
-        }
-        __syncthreads();
-        XCLK(const uint64_t xt1 = clock64(); if (attempt == 0) x_c1 += xt1 - xt0; else x_retry++;)
-        // next^2 .. next^32.  Where the 50 codes of group k end: 2 + 16 + 32, each hop as soon as its table stands -- the first two travel
-        // beside the following round's gathers, one is left behind the last barrier.
-        uint32_t hop = 0;
-#pragma unroll
-        for (int lv = 1; lv <= 5; lv++) {
-          if (wv < wa) ma = ch_ld(A, lv - 1, ma);
-          if (wv < wb) mb = ch_ld(B, lv - 1, mb);
-          if (wv < wa) ch_st(A, lv, i, ma);
-          if (wv < wb) ch_st(B, lv, i, mb);
-          __syncthreads();
-          if (lv == 1) hop = ch_ld(A, 1, 0);
-          if (lv == 4) hop = ch_ld(A, 4, hop);
-        }
-        XCLK(const uint64_t xt2 = clock64(); x_c2 += xt2 - xt1;)
-        e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch_ld(A, 5, hop)) >> 1;
-        // A chain that has left its positions STAYS on the value it left with, and a value equal to the number of positions may be such
-        // a stop in the middle of the group: only a value below it is the end of 50 codes for sure -- except on the whole span, whose
-        // last position nothing but 50 codes of the longest length reach.
-        ok0 = e0 < span || (span == full_span && e0 == span);
-        e1 = CH_NONE;
-        if (both && ok0 && e0 >= bstart && e0 - bstart < xb_w) {               // ... and from there the 50 codes of group k + 1, on B
-          e1 = ch_ld(B, 1, ch_ld(B, 4, ch_ld(B, 5, 2 * (e0 - bstart))));
-          e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e1) >> 1;
-        }
-        XCLK(x_c3 += clock64() - xt2;)
-        if (ok0 || span == full_span) break;
-        __syncthreads();                           // (everyone has read the short attempt's arrays)
+      const uint32_t cstart = min(max(base2, lp * xc_num >> 3), 2 * CH_SPAN - CH_T);
+      uint32_t span = min(full_span, CH_WIN), e0, e1, e2;
+      if (g2 >= 0) chain_tables<3>(S, len12, wbuf, A, B, C, i, o0, g, g1, g2, span, span == full_span, bstart, cstart, e0, e1, e2);
+      else if (g1 >= 0) chain_tables<2>(S, len12, wbuf, A, B, C, i, o0, g, g1, g2, span, span == full_span, bstart, cstart, e0, e1, e2);
+      else chain_tables<1>(S, len12, wbuf, A, B, C, i, o0, g, g1, g2, span, span == full_span, bstart, cstart, e0, e1, e2);
+      e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e0); e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e1); e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e2);
+      bool ok0 = e0 < span || (span == full_span && e0 == span);
+      if (!ok0 && span < full_span) {              // (uniform) group k alone on its whole span
+        XCLK(x_retry++;)
+        span = full_span;
+        e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch_ld(A, 5, chain_table_full(S, len12, wbuf, A, i, o0, g, span))) >> 1;
+        ok0 = e0 <= span;
       }
       if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
       ok_groups = k + 1;
       if (!ok0) break;                             // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
-      XCLK(x_c4 += clock64() - xt0;)
-      if (e1 < xb_w) {                             // both groups
+      if (e2 < CH_WIN) {                           // three groups
+        XCLK(x_three++;)
+        if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + bstart + e1 - data_bit); }
+        ok_groups = k + 3;
+        lp = cstart + e2 - (bstart + e1);
+        pos += cstart + e2; k += 3;
+      } else if (e1 < CH_WIN) {                    // two
         XCLK(x_two++;)
         if (tid == 0) gstart[k + 1] = (uint32_t)(pos + e0 - data_bit);
         ok_groups = k + 2;
@@ -540,7 +576,7 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
-  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[1] = x_c1; g_dec_clk[2] = x_c2; g_dec_clk[3] = x_c3; g_dec_clk[4] = x_c4; g_dec_clk[8] = clock64() - xT0; })
+  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[9] = x_three; g_dec_clk[1] = x_c1; g_dec_clk[2] = x_c2; g_dec_clk[3] = x_c3; g_dec_clk[4] = x_c4; g_dec_clk[8] = clock64() - xT0; })
   if (tid == 0) {
     T.sym_total = s_hdr[1]; T.group_count = group_count; T.n_sel = n_sel; T.err = (uint32_t)herr; T.data_bit = data_bit; T.crc = s_hdr[4]; T.orig = s_hdr[5];
     T.ngroups_ok = ok_groups; T.pad = 0; T.eob_key = ~0ull; T.err_key = ~0ull;
@@ -1305,8 +1341,8 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     uint32_t c1 = c0, rows = 0, r0 = 0;
     while (c1 < ncand && (S->cands[c1].kind != 0 || rows < nr)) { if (S->cands[c1].kind == 0) { if (!rows) r0 = S->cands[c1].pad; rows++; } c1++; }
     const uint32_t nc = c1 - c0;
-    { static const uint32_t xw = getenv("CJS_X_BW") ? (uint32_t)atoi(getenv("CJS_X_BW")) : 448u, xn = getenv("CJS_X_BNUM") ? (uint32_t)atoi(getenv("CJS_X_BNUM")) : 0u, xs = getenv("CJS_X_SHORT") ? (uint32_t)atoi(getenv("CJS_X_SHORT")) : 448u;
-    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0, xw, xn, xs); }
+    { static const uint32_t xn = getenv("CJS_X_BNUM") ? (uint32_t)atoi(getenv("CJS_X_BNUM")) : 0u, xcn = getenv("CJS_X_CNUM") ? (uint32_t)atoi(getenv("CJS_X_CNUM")) : 12u;
+    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0, xn, xcn); }
     if (rows) hipLaunchKernelGGL(bz_group_syms, dim3(group_tiles, rows), dim3(256), 0, s, S->d_in, S->up_hi, d_tabs, d_sel, d_gstart, d_syms, sym_stride, 0u);
     hipLaunchKernelGGL(bz_sym_ops, dim3(nc), dim3(1024), 0, s, d_tabs, d_cand + c0, nc, d_syms, sym_stride, dsz, d_ops, d_opoff, ops_stride, d_nops, d_bo + c0, r0, S->up_hi * 8);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data() + c0, d_bo + c0, sizeof(BlockOut) * nc, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1346,9 +1382,9 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops); S->drop(d_tabs); S->drop(d_sel); S->drop(d_gstart); S->drop(d_syms);
   if (!single) { S->drop(d_ttb); S->drop(d_gdst); }
   if (getenv("CJS_DEBUG")) {
-    uint64_t clk[9];
+    uint64_t clk[10];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
-      fprintf(stderr, "[cjs dec] X steps %llu two %llu retry %llu | cycles next1 %llu rounds %llu hops %llu step %llu total %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
+      fprintf(stderr, "[cjs dec] X steps %llu three %llu two %llu retry %llu | cycles next1 %llu rounds %llu hops %llu step %llu total %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)clk[9], (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
       fprintf(stderr, "[cjs dec] candidate 0: header + tables %.1f us, group chain %.1f us for %llu groups\n", clk[5] / 100.0, clk[6] / 100.0, (unsigned long long)clk[7]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
