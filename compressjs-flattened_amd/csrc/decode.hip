@@ -339,9 +339,12 @@ constexpr uint32_t GROUP_SYMS = 50;
 constexpr uint32_t MAX_SELECTORS = 32768;
 
 
-// bz_chain's tables: level lv of table t (uint16_t[6][CH_ARR]) by byte offset
-template <uint32_t N> __device__ __forceinline__ uint32_t ch_ld(uint16_t (*t)[N], int lv, uint32_t off) { return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(t[lv]) + off); }
-template <uint32_t N> __device__ __forceinline__ void ch_st(uint16_t (*t)[N], int lv, uint32_t i, uint32_t v) { t[lv][i] = (uint16_t)v; }
+// bz_chain's tables: level lv (next^(2^lv)) of table t by byte offset.  A level is read by the round behind it only (the hops aside: 1, 4
+// and 5), so four arrays hold the six: 0 and 3 share one, 2 and 5 another -- and the step behind writes its level 0 where this step's
+// last lookups (level 5) do not read.
+__host__ __device__ constexpr int ch_slot(int lv) { return lv == 1 ? 0 : lv == 4 ? 1 : (lv == 2 || lv == 5) ? 2 : 3; }
+template <uint32_t N> __device__ __forceinline__ uint32_t ch_ld(uint16_t (*t)[N], int lv, uint32_t off) { return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(t[ch_slot(lv)]) + off); }
+template <uint32_t N> __device__ __forceinline__ void ch_st(uint16_t (*t)[N], int lv, uint32_t i, uint32_t v) { t[ch_slot(lv)][i] = (uint16_t)v; }
 // The 20 bits at bit o of the window
 __device__ __forceinline__ uint32_t chain_bits(const uint32_t* wbuf, uint32_t o) {
   const uint32_t w0 = wbuf[o >> 5], w1 = wbuf[(o >> 5) + 1];
@@ -359,69 +362,74 @@ __device__ __forceinline__ uint32_t chain_next(const DecShared& S, int g, uint32
   for (int l = 13; l <= 19; l++) len += x20 >= S.limp[g][l] ? 1u : 0u;
   return x20 < S.limp[g][20] ? i + len : none;
 }
-// One step's tables for NT groups (k on A from its known start, k + 1 on B from bit bstart, k + 2 on C from bit cstart): next^1, then
-// five rounds of doubling.  Tables hold BYTE OFFSETS (2 x position) into a level's array, and every position behind a table's last
-// (>= 64 of them: a code is at most 20 bits) maps to itself, as does CH_NONE: a chain that has left its positions, or met one where no
-// code starts, stays where it is without a compare -- a round is one gather and one store per table, all threads on all tables, no
-// branch (the kernel's scalar unit serves every wave's branches and address arithmetic: with one thread per position and table, and
-// a branch around each, those instructions outnumbered the vector ones three to one and set the pace).  e0 / e1 / e2: where the groups
-// end, in positions of A / B / C (every lane the same value; CH_NONE or beyond a table's positions: not known from this step).  Group k's
-// 50 codes are 2 + 16 + 32: the first two hops as soon as their table stands, beside the following round's gathers.
+// One step's tables for NT groups (k on A from its known start, k + q on L[q - 1] from bit start[q - 1] of the step): next^1, then five
+// rounds of doubling.  Tables hold BYTE OFFSETS (2 x position) into a level's array, and every position behind a table's last (>= 64 of
+// them: a code is at most 20 bits) maps to itself, as does CH_NONE: a chain that has left its positions, or met one where no code
+// starts, stays where it is without a compare -- a round is one gather and one store per table, all threads on all tables, no branch
+// (the CU's scalar unit serves every wave's branches and address arithmetic: with one thread per position and table, and a branch
+// around each, those instructions outnumbered the vector ones three to one and set the pace).  e[q]: where group k + q ends, in
+// positions of its table (every lane the same value; CH_NONE / CH_NONE2 or beyond the table's positions: not known from this step).
+// Group k's 50 codes are 2 + 16 + 32: the first two hops as soon as their table stands, beside the following round's gathers.
+struct ChainLater { uint16_t (*t)[CH_ARR2]; int g; uint32_t start; };
 template <int NT>
-__device__ __forceinline__ void chain_tables(const DecShared& S, const uint8_t (*len12)[4096], const uint32_t* wbuf, uint16_t (*A)[CH_ARR], uint16_t (*B)[CH_ARR2], uint16_t (*C)[CH_ARR2],
-                                                 uint32_t i, uint32_t o0, int g, int g1, int g2, uint32_t span, bool whole, uint32_t bstart, uint32_t cstart,
-                                                 uint32_t& e0, uint32_t& e1, uint32_t& e2) {
-  // (the tables' loads side by side: two LDS latencies for the three, not six)
-  const uint32_t xa = chain_bits(wbuf, o0 + i), xb = NT >= 2 ? chain_bits(wbuf, o0 + bstart + i) : 0u, xc = NT >= 3 ? chain_bits(wbuf, o0 + cstart + i) : 0u;
-  const uint32_t ea = len12[g][xa >> 8], eb = NT >= 2 ? len12[g1][xb >> 8] : 1u, ec = NT >= 3 ? len12[g2][xc >> 8] : 1u;
-  uint32_t ma = chain_next(S, g, ea, xa, i, CH_NONE), mb = 0, mc = 0;
-  ma = 2 * (i < span ? ma : i);
-  if (NT >= 2) { mb = chain_next(S, g1, eb, xb, i, CH_NONE2); mb = 2 * (i < CH_WIN ? mb : i); }
-  if (NT >= 3) { mc = chain_next(S, g2, ec, xc, i, CH_NONE2); mc = 2 * (i < CH_WIN ? mc : i); }
-  ch_st(A, 0, i, ma);
-  if (NT >= 2) ch_st(B, 0, i, mb);
-  if (NT >= 3) ch_st(C, 0, i, mc);
+__device__ __forceinline__ void chain_tables(const DecShared& S, const uint8_t (*len12)[4096], const uint32_t* wbuf, uint16_t (*A)[CH_ARR], const ChainLater (&L)[3],
+                                             uint32_t i, uint32_t o0, int g, uint32_t span, bool whole, uint32_t (&e)[4]) {
+  // (the tables' loads side by side: two LDS latencies for all of them)
+  uint32_t x[NT], en[NT], m[NT];
+  x[0] = chain_bits(wbuf, o0 + i);
+#pragma unroll
+  for (int q = 1; q < NT; q++) x[q] = chain_bits(wbuf, o0 + L[q - 1].start + i);
+  en[0] = len12[g][x[0] >> 8];
+#pragma unroll
+  for (int q = 1; q < NT; q++) en[q] = len12[L[q - 1].g][x[q] >> 8];
+  m[0] = chain_next(S, g, en[0], x[0], i, CH_NONE);
+  m[0] = 2 * (i < span ? m[0] : i);
+#pragma unroll
+  for (int q = 1; q < NT; q++) { m[q] = chain_next(S, L[q - 1].g, en[q], x[q], i, CH_NONE2); m[q] = 2 * (i < CH_WIN ? m[q] : i); }
+  ch_st(A, 0, i, m[0]);
+#pragma unroll
+  for (int q = 1; q < NT; q++) ch_st(L[q - 1].t, 0, i, m[q]);
   __syncthreads();
   uint32_t hop = 0;
 #pragma unroll
   for (int lv = 1; lv <= 4; lv++) {
-    ma = ch_ld(A, lv - 1, ma);
-    if (NT >= 2) mb = ch_ld(B, lv - 1, mb);
-    if (NT >= 3) mc = ch_ld(C, lv - 1, mc);
-    ch_st(A, lv, i, ma);
-    if (NT >= 2) ch_st(B, lv, i, mb);
-    if (NT >= 3) ch_st(C, lv, i, mc);
+    m[0] = ch_ld(A, lv - 1, m[0]);
+#pragma unroll
+    for (int q = 1; q < NT; q++) m[q] = ch_ld(L[q - 1].t, lv - 1, m[q]);
+    ch_st(A, lv, i, m[0]);
+#pragma unroll
+    for (int q = 1; q < NT; q++) ch_st(L[q - 1].t, lv, i, m[q]);
     __syncthreads();
     if (lv == 1) hop = ch_ld(A, 1, 0);
     if (lv == 4) hop = ch_ld(A, 4, hop);
   }
-  // The last round: A's next^32 (one hop is left for it), but B's and C's next^50 = next^2 . next^16 . next^32 outright: two more gathers
-  // here (every position at once) instead of two more hops each behind the barrier (one after the other).
-  ma = ch_ld(A, 4, ma);
-  if (NT >= 2) mb = ch_ld(B, 4, mb);
-  if (NT >= 3) mc = ch_ld(C, 4, mc);
-  ch_st(A, 5, i, ma);
-  if (NT >= 2) mb = ch_ld(B, 4, mb);
-  if (NT >= 3) mc = ch_ld(C, 4, mc);
-  if (NT >= 2) mb = ch_ld(B, 1, mb);
-  if (NT >= 3) mc = ch_ld(C, 1, mc);
-  if (NT >= 2) ch_st(B, 5, i, mb);
-  if (NT >= 3) ch_st(C, 5, i, mc);
+  // The last round: A's next^32 (one hop is left for it), but the later tables' next^50 = next^2 . next^16 . next^32 outright: two more
+  // gathers here (every position at once) instead of two more hops each behind the barrier (one after the other).
+  m[0] = ch_ld(A, 4, m[0]);
+#pragma unroll
+  for (int q = 1; q < NT; q++) m[q] = ch_ld(L[q - 1].t, 4, m[q]);
+  ch_st(A, 5, i, m[0]);
+#pragma unroll
+  for (int q = 1; q < NT; q++) m[q] = ch_ld(L[q - 1].t, 4, m[q]);
+#pragma unroll
+  for (int q = 1; q < NT; q++) m[q] = ch_ld(L[q - 1].t, 1, m[q]);
+#pragma unroll
+  for (int q = 1; q < NT; q++) ch_st(L[q - 1].t, 5, i, m[q]);
   __syncthreads();
   // Where the groups end.  A chain that has left its positions STAYS on the value it left with, and a value equal to the number of
   // positions may be such a stop in the middle of the group: only a value below it is the end of 50 codes for sure -- except on the
   // whole span, whose last position nothing but 50 codes of the longest length reach.  A group that starts outside its table's
-  // positions is looked up at CH_NONE, which maps to itself.
-  e0 = ch_ld(A, 5, hop) >> 1;
-  e1 = e2 = CH_NONE2;
-  if (NT >= 2) {
-    const bool in_b = (e0 < span || (whole && e0 == span)) && e0 >= bstart && e0 - bstart < CH_WIN;
-    e1 = ch_ld(B, 5, 2 * (in_b ? e0 - bstart : CH_NONE2)) >> 1;
-  }
-  if (NT >= 3) {
-    const uint32_t s2 = bstart + e1;
-    const bool in_c = e1 < CH_WIN && s2 >= cstart && s2 - cstart < CH_WIN;
-    e2 = ch_ld(C, 5, 2 * (in_c ? s2 - cstart : CH_NONE2)) >> 1;
+  // positions is looked up at CH_NONE2, which maps to itself.
+  e[0] = ch_ld(A, 5, hop) >> 1;
+  e[1] = e[2] = e[3] = CH_NONE2;
+  bool known = e[0] < span || (whole && e[0] == span);
+  uint32_t at = e[0];                            // where the group in front ends, in bits of the step
+#pragma unroll
+  for (int q = 1; q < NT; q++) {
+    const bool in = known && at >= L[q - 1].start && at - L[q - 1].start < CH_WIN;
+    e[q] = ch_ld(L[q - 1].t, 5, 2 * (in ? at - L[q - 1].start : CH_NONE2)) >> 1;
+    known = e[q] < CH_WIN;
+    at = L[q - 1].start + e[q];
   }
 }
 // The same for group k alone on its whole span (two positions per thread)
@@ -446,13 +454,12 @@ __device__ __forceinline__ uint32_t chain_table_full(const DecShared& S, const u
 
 __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
-                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0, uint32_t xb_num, uint32_t xc_num) {
+                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0, uint32_t xb_num, uint32_t xc_num, uint32_t xd_num) {
   __shared__ DecShared S;
-  __shared__ uint32_t scratch[6 * CH_ARR / 2 + 12 * CH_ARR2 / 2 + CH_WORDS + 2];         // the prologue's selector values (4096 words), then the chain's arrays
-  uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);                     // group k:     next^(2^lv), lv = 0 .. 5
-  uint16_t (*B)[CH_ARR2] = reinterpret_cast<uint16_t (*)[CH_ARR2]>(scratch + 6 * CH_ARR / 2);                    // group k + 1
-  uint16_t (*C)[CH_ARR2] = reinterpret_cast<uint16_t (*)[CH_ARR2]>(scratch + 6 * CH_ARR / 2 + 6 * CH_ARR2 / 2);   // group k + 2
-  uint32_t* wbuf = scratch + 6 * CH_ARR / 2 + 12 * CH_ARR2 / 2;
+  __shared__ uint32_t scratch[4 * CH_ARR / 2 + 12 * CH_ARR2 / 2 + CH_WORDS + 2];         // the prologue's selector values (4096 words), then the chain's arrays
+  uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);                     // group k: next^(2^lv), lv = 0 .. 5, in four arrays (ch_slot)
+  uint16_t (*B)[CH_ARR2] = reinterpret_cast<uint16_t (*)[CH_ARR2]>(scratch + 4 * CH_ARR / 2);                    // groups k + 1, k + 2, k + 3: four arrays each
+  uint32_t* wbuf = scratch + 4 * CH_ARR / 2 + 12 * CH_ARR2 / 2;
   __shared__ uint8_t len12[6][4096];            // code length by the next 12 bits (chain_next)
   __shared__ uint64_t s_pos;
   __shared__ uint32_t s_hdr[8];
@@ -502,10 +509,10 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
     }
   }
   // (the positions behind the last a thread writes, once for every level)
-  if (tid < 64) for (int lv = 0; lv < 6; lv++) { A[lv][CH_SPAN + tid] = (uint16_t)(2 * (CH_SPAN + tid)); B[lv][CH_T + tid] = C[lv][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); }
+  if (tid < 64) { for (int a = 0; a < 4; a++) A[a][CH_SPAN + tid] = (uint16_t)(2 * (CH_SPAN + tid)); for (int a = 0; a < 12; a++) B[a][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); }
   __syncthreads();
   uint32_t ok_groups = 0;
-  XCLK(uint64_t x_steps = 0, x_two = 0, x_three = 0, x_retry = 0, x_c1 = 0, x_c2 = 0, x_c3 = 0, x_c4 = 0; const uint64_t xT0 = clock64();)
+  XCLK(uint64_t x_steps = 0, x_two = 0, x_three = 0, x_four = 0, x_retry = 0, x_c1 = 0, x_c2 = 0, x_c3 = 0, x_c4 = 0; const uint64_t xT0 = clock64();)
   if (!herr) {
     uint64_t pos = data_bit, wbase = ~0ull;      // wbase: stream word at wbuf[0]
     // Nothing the step's first instructions need comes from memory: the tables' shortest / longest lengths sit in two registers (5 bits
@@ -531,9 +538,11 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       // that leaves its table's positions, or starts in front of them, simply is the first group of the next step.
       const int g1 = k + 1 < n_sel ? (kj < 63 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 1) & 63)) : __builtin_amdgcn_readlane((int)shi, 0)) : -1;
       const int g2 = k + 2 < n_sel ? (kj < 62 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 2) & 63)) : __builtin_amdgcn_readlane((int)shi, (int)((kj + 2) & 63))) : -1;
+      const int g3 = k + 3 < n_sel ? (kj < 61 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 3) & 63)) : __builtin_amdgcn_readlane((int)shi, (int)((kj + 3) & 63))) : -1;
       const uint32_t full_span = min(GROUP_SYMS * ((maxp >> (5 * g)) & 31u), CH_SPAN);
       const uint32_t base1 = GROUP_SYMS * ((minp >> (5 * g)) & 31u);        // group k + 1 starts at or behind this offset
-      const uint32_t base2 = base1 + (g1 >= 0 ? GROUP_SYMS * ((minp >> (5 * g1)) & 31u) : 0u);      // ... and group k + 2 at or behind this one
+      const uint32_t base2 = base1 + (g1 >= 0 ? GROUP_SYMS * ((minp >> (5 * g1)) & 31u) : 0u);      // ... group k + 2 at or behind this one
+      const uint32_t base3 = base2 + (g2 >= 0 ? GROUP_SYMS * ((minp >> (5 * g2)) & 31u) : 0u);      // ... and group k + 3 here
       if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + 2 * CH_SPAN + 128) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
         __syncthreads();
         wbase = pos >> 5;
@@ -543,13 +552,16 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
       XCLK(x_steps++;)
       const uint32_t i = (uint32_t)tid;
-      const uint32_t bstart = min(max(base1, lp * xb_num >> 3), CH_SPAN);
-      const uint32_t cstart = min(max(base2, lp * xc_num >> 3), 2 * CH_SPAN - CH_T);
-      uint32_t span = min(full_span, CH_WIN), e0, e1, e2;
-      if (g2 >= 0) chain_tables<3>(S, len12, wbuf, A, B, C, i, o0, g, g1, g2, span, span == full_span, bstart, cstart, e0, e1, e2);
-      else if (g1 >= 0) chain_tables<2>(S, len12, wbuf, A, B, C, i, o0, g, g1, g2, span, span == full_span, bstart, cstart, e0, e1, e2);
-      else chain_tables<1>(S, len12, wbuf, A, B, C, i, o0, g, g1, g2, span, span == full_span, bstart, cstart, e0, e1, e2);
-      e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e0); e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e1); e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e2);
+      const ChainLater L[3] = {{B, g1, min(max(base1, lp * xb_num >> 3), CH_SPAN)},
+                               {B + 4, g2, min(max(base2, lp * xc_num >> 3), 2 * CH_SPAN - CH_T)},
+                               {B + 8, g3, min(max(base3, lp * xd_num >> 3), 2 * CH_SPAN - CH_T)}};
+      uint32_t span = min(full_span, CH_WIN), e[4];
+      if (g3 >= 0) chain_tables<4>(S, len12, wbuf, A, L, i, o0, g, span, span == full_span, e);
+      else if (g2 >= 0) chain_tables<3>(S, len12, wbuf, A, L, i, o0, g, span, span == full_span, e);
+      else if (g1 >= 0) chain_tables<2>(S, len12, wbuf, A, L, i, o0, g, span, span == full_span, e);
+      else chain_tables<1>(S, len12, wbuf, A, L, i, o0, g, span, span == full_span, e);
+      uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]);
+      const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]), e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[2]), e3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[3]);
       bool ok0 = e0 < span || (span == full_span && e0 == span);
       if (!ok0 && span < full_span) {              // (uniform) group k alone on its whole span
         XCLK(x_retry++;)
@@ -560,23 +572,30 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
       ok_groups = k + 1;
       if (!ok0) break;                             // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
-      if (e2 < CH_WIN) {                           // three groups
+      // (a later group's end is known only if those in front of it are: chain_tables)
+      if (e3 < CH_WIN) {                           // four groups
+        XCLK(x_four++;)
+        if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + L[0].start + e1 - data_bit); gstart[k + 3] = (uint32_t)(pos + L[1].start + e2 - data_bit); }
+        ok_groups = k + 4;
+        lp = L[2].start + e3 - (L[1].start + e2);
+        pos += L[2].start + e3; k += 4;
+      } else if (e2 < CH_WIN) {                    // three
         XCLK(x_three++;)
-        if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + bstart + e1 - data_bit); }
+        if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + L[0].start + e1 - data_bit); }
         ok_groups = k + 3;
-        lp = cstart + e2 - (bstart + e1);
-        pos += cstart + e2; k += 3;
+        lp = L[1].start + e2 - (L[0].start + e1);
+        pos += L[1].start + e2; k += 3;
       } else if (e1 < CH_WIN) {                    // two
         XCLK(x_two++;)
         if (tid == 0) gstart[k + 1] = (uint32_t)(pos + e0 - data_bit);
         ok_groups = k + 2;
-        lp = bstart + e1 - e0;
-        pos += bstart + e1; k += 2;
+        lp = L[0].start + e1 - e0;
+        pos += L[0].start + e1; k += 2;
       } else { lp = e0; pos += e0; k += 1; }                // (the second group left B's positions, met an undecodable position, or there was none: next step)
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
-  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[9] = x_three; g_dec_clk[1] = x_c1; g_dec_clk[2] = x_c2; g_dec_clk[3] = x_c3; g_dec_clk[4] = x_c4; g_dec_clk[8] = clock64() - xT0; })
+  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[9] = x_three | (x_four << 32); g_dec_clk[1] = x_c1; g_dec_clk[2] = x_c2; g_dec_clk[3] = x_c3; g_dec_clk[4] = x_c4; g_dec_clk[8] = clock64() - xT0; })
   if (tid == 0) {
     T.sym_total = s_hdr[1]; T.group_count = group_count; T.n_sel = n_sel; T.err = (uint32_t)herr; T.data_bit = data_bit; T.crc = s_hdr[4]; T.orig = s_hdr[5];
     T.ngroups_ok = ok_groups; T.pad = 0; T.eob_key = ~0ull; T.err_key = ~0ull;
@@ -1341,8 +1360,8 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     uint32_t c1 = c0, rows = 0, r0 = 0;
     while (c1 < ncand && (S->cands[c1].kind != 0 || rows < nr)) { if (S->cands[c1].kind == 0) { if (!rows) r0 = S->cands[c1].pad; rows++; } c1++; }
     const uint32_t nc = c1 - c0;
-    { static const uint32_t xn = getenv("CJS_X_BNUM") ? (uint32_t)atoi(getenv("CJS_X_BNUM")) : 0u, xcn = getenv("CJS_X_CNUM") ? (uint32_t)atoi(getenv("CJS_X_CNUM")) : 12u;
-    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0, xn, xcn); }
+    { static const uint32_t xn = getenv("CJS_X_BNUM") ? (uint32_t)atoi(getenv("CJS_X_BNUM")) : 0u, xcn = getenv("CJS_X_CNUM") ? (uint32_t)atoi(getenv("CJS_X_CNUM")) : 12u, xdn = getenv("CJS_X_DNUM") ? (uint32_t)atoi(getenv("CJS_X_DNUM")) : 20u;
+    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0, xn, xcn, xdn); }
     if (rows) hipLaunchKernelGGL(bz_group_syms, dim3(group_tiles, rows), dim3(256), 0, s, S->d_in, S->up_hi, d_tabs, d_sel, d_gstart, d_syms, sym_stride, 0u);
     hipLaunchKernelGGL(bz_sym_ops, dim3(nc), dim3(1024), 0, s, d_tabs, d_cand + c0, nc, d_syms, sym_stride, dsz, d_ops, d_opoff, ops_stride, d_nops, d_bo + c0, r0, S->up_hi * 8);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data() + c0, d_bo + c0, sizeof(BlockOut) * nc, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1384,7 +1403,7 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (getenv("CJS_DEBUG")) {
     uint64_t clk[10];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
-      fprintf(stderr, "[cjs dec] X steps %llu three %llu two %llu retry %llu | cycles next1 %llu rounds %llu hops %llu step %llu total %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)clk[9], (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
+      fprintf(stderr, "[cjs dec] X steps %llu four %llu three %llu two %llu retry %llu | cycles next1 %llu rounds %llu hops %llu step %llu total %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)(clk[9] >> 32), (unsigned long long)(clk[9] & 0xFFFFFFFFu), (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
       fprintf(stderr, "[cjs dec] candidate 0: header + tables %.1f us, group chain %.1f us for %llu groups\n", clk[5] / 100.0, clk[6] / 100.0, (unsigned long long)clk[7]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
