@@ -145,6 +145,23 @@ struct BitWin {
 
 // Block header and code lengths (lane 0, serial), selector list and decode tables (whole wave).  Executed by ONE wave; the results
 // are wave-uniform scalars.  Returns 0 or a CJS_E_* code.  `selp`: LDS scratch of 4096 words (the unary values, a nibble each).
+__device__ uint64_t g_dec_clk[10];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
+#ifdef XV_CLK
+#define XCLK(...) __VA_ARGS__
+#else
+#define XCLK(...)
+#endif
+// a list of eight nibbles: nibble j to the front / the list x read at the positions y holds
+__device__ __forceinline__ uint32_t nib_to_front(uint32_t st, uint32_t j) {
+  const uint32_t val = (st >> (4u * j)) & 15u, low = st & ((1u << (4u * j)) - 1u);
+  return (st & ~((1u << (4u * j + 4u)) - 1u)) | (low << 4) | val;
+}
+__device__ __forceinline__ uint32_t nib_compose(uint32_t x, uint32_t y) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int p = 0; p < 8; p++) r |= ((x >> (4u * ((y >> (4 * p)) & 15u))) & 15u) << (4 * p);
+  return r;
+}
 __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint32_t& crc, uint32_t& orig, uint32_t& sym_total,
                             uint32_t& group_count, uint32_t& n_sel, uint8_t* __restrict__ selectors /* global, room for 32768 */, uint32_t* __restrict__ selp) {
   int err = 0;
@@ -167,7 +184,8 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     if (!err && n_sel == 0) err = CJS_E_DATA_ERROR;
   }
   err = __builtin_amdgcn_readfirstlane(err);
-  group_count = __builtin_amdgcn_readfirstlane(group_count); n_sel = __builtin_amdgcn_readfirstlane(n_sel);
+  group_count = __builtin_amdgcn_readfirstlane(group_count); n_sel = __builtin_amdgcn_readfirstlane(n_sel); sym_total = __builtin_amdgcn_readfirstlane(sym_total);
+  XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[1] = wall_clock64();)
   uint64_t pos = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
   if (!err) {
     // Selector list (:1487-1493): n_sel unary numbers (ones closed by a zero).  Every lane takes 32 bits of a 2048-bit stretch:
@@ -205,39 +223,95 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
       } else { done += total; carry = (uint32_t)__builtin_amdgcn_readlane((int)t1, 63); pos += 2048; }
     }
     if (__ballot(bad != 0)) err = CJS_E_DATA_ERROR;
+    XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[2] = wall_clock64();)
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      if (!err) {                                            // move-to-front over the values: the list as nibbles of one register
-        uint32_t st = 0;
-        for (uint32_t i = 0; i < group_count; i++) st |= i << (4u * i);
-        uint32_t wv = 0;
-        for (uint32_t i = 0; i < n_sel; i++) {
-          if ((i & 7u) == 0) wv = selp[i >> 3];
-          const uint32_t j = wv & 15u; wv >>= 4;
-          const uint32_t val = (st >> (4u * j)) & 15u, low = st & ((1u << (4u * j)) - 1u);
-          st = (st & ~((1u << (4u * j + 4u)) - 1u)) | (low << 4) | val;
-          selectors[i] = (uint8_t)val;
-        }
+    if (!err) {
+      // Move-to-front over the values, the list as nibbles of one register.  A stretch of the list acts on the positions as a
+      // permutation whatever they hold: every lane composes its stretch's (from the identity), a scan composes those in front of each
+      // lane, and a second walk from the list the lane really starts with writes the selectors.  (Position group_count holds the
+      // zero of the reference's zero-initialised list: a value equal to the count reads it, and moves it.)
+      const uint32_t cs = (((n_sel + 63u) >> 6) + 7u) & ~7u;             // values per lane: whole words of selp
+      const uint32_t c0 = min((uint32_t)lane * cs, n_sel), c1 = min(c0 + cs, n_sel);
+      uint32_t R = 0x76543210u, wv = 0;
+      for (uint32_t i = c0; i < c1; i++) {
+        if ((i & 7u) == 0) wv = selp[i >> 3];
+        R = nib_to_front(R, wv & 15u); wv >>= 4;
       }
-      r.pos = endpos > r.nbits ? r.nbits : endpos;
-    }
-  }
-  if (lane == 0) {
-    if (!err) {                                              // code lengths (:1500-1520)
-      const uint32_t sym_count = sym_total + 2;
-      for (uint32_t g = 0; g < group_count && !err; g++) {
-        int t5 = (int)r.get(5);
-        for (uint32_t i = 0; i < sym_count && !err; i++) {
-          for (;;) {
-            if (t5 < 1 || t5 > 20) { err = CJS_E_DATA_ERROR; break; }
-            if (!r.get(1)) break;
-            if (!r.get(1)) t5++; else t5--;
-          }
-          S.length[g][i] = (uint8_t)t5;
-        }
+      uint32_t I = R;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)I, d, 64);
+        if (lane >= d) I = nib_compose(up, I);
+      }
+      uint32_t E = (uint32_t)__shfl_up((int)I, 1, 64);
+      if (lane == 0) E = 0x76543210u;
+      uint32_t st = 0;
+      for (uint32_t i = 0; i < group_count; i++) st |= i << (4u * i);
+      st = nib_compose(st, E);
+      for (uint32_t i = c0; i < c1; i++) {
+        if ((i & 7u) == 0) wv = selp[i >> 3];
+        const uint32_t j = wv & 15u; wv >>= 4;
+        selectors[i] = (uint8_t)((st >> (4u * j)) & 15u);
+        st = nib_to_front(st, j);
       }
     }
+    pos = endpos > r.nbits ? r.nbits : endpos;
   }
+  XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[3] = wall_clock64();)
+  if (!err) {
+    // Code lengths (:1500-1520): per table 5 bits, then per symbol a run of (1, direction) pairs closed by a 0.  Behind a 0 and behind
+    // a direction bit stands a control bit, so in a run of ones the bits alternate control / direction from the run's first (a control
+    // bit): what a lane's first bit is follows from the parity of the ones in front of it.  Every lane walks 32 bits of a 2048-bit
+    // stretch twice: once for its count of symbol ends and its sum of steps, and -- with the sums of the lanes in front -- once more
+    // to write the lengths.  The reference tests the running length wherever it has changed (and where a table starts): 1 .. 20.
+    const uint64_t nbytes = (r.nbits + 7) >> 3;
+    const uint32_t sym_count0 = sym_total + 2;
+    int bad = 0;
+    for (uint32_t g = 0; g < group_count && !__ballot(bad != 0); g++) {
+      int cur0;
+      { const uint32_t w0 = load_be32(r.p, nbytes, pos >> 5), w1 = load_be32(r.p, nbytes, (pos >> 5) + 1);
+        cur0 = (int)((((((uint64_t)w0 << 32) | w1) << (pos & 31)) >> 59)); pos += 5; }
+      if (cur0 < 1 || cur0 > 20) bad = 1;
+      uint32_t done = 0, par_in = 0;
+      for (;;) {
+        const uint64_t bp = pos + 32u * (uint32_t)lane;
+        const uint32_t w0 = load_be32(r.p, nbytes, bp >> 5), w1 = load_be32(r.p, nbytes, (bp >> 5) + 1);
+        const uint32_t v = (uint32_t)(((((uint64_t)w0 << 32) | w1) << (bp & 31)) >> 32);
+        const uint32_t t1 = v == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~v);
+        const uint64_t m_ao = __ballot(v == 0xFFFFFFFFu), m_par = __ballot((t1 & 1u) != 0);
+        const uint64_t below = ~m_ao & ((1ull << lane) - 1ull);
+        const uint32_t par = below ? (uint32_t)((m_par >> (63 - __builtin_clzll(below))) & 1ull) : par_in;      // 1: my first bit is a direction bit
+        uint32_t state = par, ne = 0; int nd = 0;
+        for (int b = 31; b >= 0; b--) {
+          const uint32_t bit = (v >> b) & 1u;
+          if (state) { nd += bit ? -1 : 1; state = 0; }
+          else if (bit) state = 1;
+          else ne++;
+        }
+        const uint32_t ie = wave_incl_sum(ne); const int id = wave_incl_sum(nd);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)ie, 63);
+        uint32_t idx = done + ie - ne; int cur = cur0 + id - nd; uint64_t endpos = 0;
+        state = par;
+        for (int b = 31; b >= 0 && idx < sym_count0; b--) {
+          const uint32_t bit = (v >> b) & 1u;
+          if (state) { cur += bit ? -1 : 1; if (cur < 1 || cur > 20) bad = 1; state = 0; }
+          else if (bit) state = 1;
+          else { S.length[g][idx] = (uint8_t)cur; if (++idx == sym_count0) endpos = bp + (uint32_t)(32 - b); }
+        }
+        if (__ballot(bad != 0)) break;                                   // (the reference stops at the first length out of range; so must a stretch of ones)
+        if (done + total >= sym_count0) {                                // the lane that wrote the last length knows where the table ends
+          const int l = (int)__builtin_ctzll(__ballot(done + ie >= sym_count0));
+          pos = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)endpos, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(endpos >> 32), l) << 32);
+          break;
+        }
+        done += total; cur0 += __builtin_amdgcn_readlane(id, 63);
+        if (~m_ao) par_in = (uint32_t)((m_par >> (63 - __builtin_clzll(~m_ao))) & 1ull);
+        pos += 2048;
+      }
+    }
+    if (__ballot(bad != 0)) err = CJS_E_DATA_ERROR;
+  }
+  if (lane == 0) r.pos = pos > r.nbits ? r.nbits : pos;
   // lane 0's results become wave-uniform scalars (readfirstlane, not a shuffle: the compiler must KNOW they are uniform,
   // or the whole symbol loop is compiled as divergent code under exec masks)
   err = __builtin_amdgcn_readfirstlane(err);
@@ -245,6 +319,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   n_sel = __builtin_amdgcn_readfirstlane(n_sel);
   const uint32_t sym_count = sym_total + 2;
   __builtin_amdgcn_wave_barrier();
+  XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[4] = wall_clock64();)
   if (!err) {
     // canonical tables: lane g builds table g -- a counting sort of the symbols by length, then the first codes
     if ((uint32_t)lane < group_count) {
@@ -287,12 +362,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   return err;
 }
 
-__device__ uint64_t g_dec_clk[10];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
-#ifdef XV_CLK
-#define XCLK(...) __VA_ARGS__
-#else
-#define XCLK(...)
-#endif
 #define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
 // ---------------------------------------------------------------- 2b. block decode in stages
 // The Huffman chain of a block looks serial -- the table changes every 50 symbols, so there is no self-synchronisation to exploit
@@ -487,7 +556,7 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   __threadfence_block();
   __syncthreads();
   const uint64_t t_hdr = wall_clock64();
-  if (tid == 0 && blockIdx.x == 0) g_dec_clk[5] = t_hdr - t_k0;
+  if (tid == 0 && blockIdx.x == 0) { g_dec_clk[5] = t_hdr - t_k0; XCLK(g_dec_clk[1] -= t_k0; g_dec_clk[2] -= t_k0; g_dec_clk[3] -= t_k0; g_dec_clk[4] -= t_k0;) }
   const int herr = (int)s_hdr[0];
   const uint32_t group_count = s_hdr[2], n_sel = s_hdr[3];
   const uint64_t data_bit = s_pos;
@@ -595,7 +664,7 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
-  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[9] = x_three | (x_four << 32); g_dec_clk[1] = x_c1; g_dec_clk[2] = x_c2; g_dec_clk[3] = x_c3; g_dec_clk[4] = x_c4; g_dec_clk[8] = clock64() - xT0; })
+  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[9] = x_three | (x_four << 32); g_dec_clk[8] = clock64() - xT0; })
   if (tid == 0) {
     T.sym_total = s_hdr[1]; T.group_count = group_count; T.n_sel = n_sel; T.err = (uint32_t)herr; T.data_bit = data_bit; T.crc = s_hdr[4]; T.orig = s_hdr[5];
     T.ngroups_ok = ok_groups; T.pad = 0; T.eob_key = ~0ull; T.err_key = ~0ull;
@@ -1403,7 +1472,7 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (getenv("CJS_DEBUG")) {
     uint64_t clk[10];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
-      fprintf(stderr, "[cjs dec] X steps %llu four %llu three %llu two %llu retry %llu | cycles next1 %llu rounds %llu hops %llu step %llu total %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)(clk[9] >> 32), (unsigned long long)(clk[9] & 0xFFFFFFFFu), (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
+      fprintf(stderr, "[cjs dec] X steps %llu four %llu three %llu two %llu retry %llu | prologue marks (10 ns) %llu %llu %llu %llu; chain cycles %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)(clk[9] >> 32), (unsigned long long)(clk[9] & 0xFFFFFFFFu), (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
       fprintf(stderr, "[cjs dec] candidate 0: header + tables %.1f us, group chain %.1f us for %llu groups\n", clk[5] / 100.0, clk[6] / 100.0, (unsigned long long)clk[7]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
