@@ -107,7 +107,6 @@ struct DecShared {
   uint16_t cnt[6][22];             // symbols of each length
   uint16_t start[6][22];           // index of the first symbol of each length in bysym
   uint16_t bysym[6][260];          // symbols ordered by (length, symbol)
-  uint16_t fast[6][1024];          // (sym << 5) | len, 0 = not decodable within 10 bits
   uint8_t minlen[8], maxlen[8];
   uint8_t length[6][260];
   uint8_t sym_to_byte[256];
@@ -341,19 +340,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
       }
       S.limp[g][0] = 0;
     }
-    __builtin_amdgcn_wave_barrier();
-    // 10-bit direct tables: entry x = the code that is a prefix of the 10 bits x, if it has one of <= 10 bits
-    for (uint32_t g = 0; g < group_count; g++) {
-      const int mn = S.minlen[g], mx = S.maxlen[g];
-      for (int x = lane; x < 1024; x += 64) {
-        uint16_t e = 0;
-        for (int i = mn; i <= 10 && i <= mx; i++) {
-          const uint32_t k = ((uint32_t)x >> (10 - i)) - S.first[g][i];      // (not below first: no shorter code matched)
-          if (k < S.cnt[g][i]) { e = (uint16_t)((S.bysym[g][S.start[g][i] + k] << 5) | i); break; }
-        }
-        S.fast[g][x] = e;
-      }
-    }
   }
   __builtin_amdgcn_wave_barrier();
   crc = __builtin_amdgcn_readfirstlane(crc);
@@ -561,7 +547,19 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   const uint32_t group_count = s_hdr[2], n_sel = s_hdr[3];
   const uint64_t data_bit = s_pos;
   // the tables go to global memory for the symbol stage
-  for (uint32_t i = tid; i < 6 * 1024; i += CH_T) (&T.fast[0][0])[i] = (&S.fast[0][0])[i];
+  // ... with the 10-bit direct tables: entry x = the code that is a prefix of the 10 bits x, if it has one of <= 10 bits
+  if (!herr) {
+    for (uint32_t e = tid; e < group_count * 1024u; e += CH_T) {
+      const uint32_t t = e >> 10, x = e & 1023u;
+      const int mn = S.minlen[t], mx = S.maxlen[t];
+      uint16_t v = 0;
+      for (int l = mn; l <= 10 && l <= mx; l++) {
+        const uint32_t k = (x >> (10 - l)) - S.first[t][l];              // (not below first: no shorter code matched)
+        if (k < S.cnt[t][l]) { v = (uint16_t)((S.bysym[t][S.start[t][l] + k] << 5) | l); break; }
+      }
+      T.fast[t][x] = v;
+    }
+  }
   for (uint32_t i = tid; i < 6 * 22; i += CH_T) { (&T.first[0][0])[i] = (&S.first[0][0])[i]; (&T.cnt[0][0])[i] = (&S.cnt[0][0])[i]; (&T.start[0][0])[i] = (&S.start[0][0])[i]; }
   for (uint32_t i = tid; i < 6 * 260; i += CH_T) (&T.bysym[0][0])[i] = (&S.bysym[0][0])[i];
   if (tid < 8) { T.minlen[tid] = S.minlen[tid]; T.maxlen[tid] = S.maxlen[tid]; }
