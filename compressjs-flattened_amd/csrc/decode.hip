@@ -144,12 +144,7 @@ struct BitWin {
 
 // Block header and code lengths (lane 0, serial), selector list and decode tables (whole wave).  Executed by ONE wave; the results
 // are wave-uniform scalars.  Returns 0 or a CJS_E_* code.  `selp`: LDS scratch of 4096 words (the unary values, a nibble each).
-__device__ uint64_t g_dec_clk[10];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
-#ifdef XV_CLK
-#define XCLK(...) __VA_ARGS__
-#else
-#define XCLK(...)
-#endif
+__device__ uint64_t g_dec_clk[8];      // phase clock of candidate 0 (CJS_DEBUG): 100 MHz ticks
 // a list of eight nibbles: nibble j to the front / the list x read at the positions y holds
 __device__ __forceinline__ uint32_t nib_to_front(uint32_t st, uint32_t j) {
   const uint32_t val = (st >> (4u * j)) & 15u, low = st & ((1u << (4u * j)) - 1u);
@@ -184,7 +179,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   }
   err = __builtin_amdgcn_readfirstlane(err);
   group_count = __builtin_amdgcn_readfirstlane(group_count); n_sel = __builtin_amdgcn_readfirstlane(n_sel); sym_total = __builtin_amdgcn_readfirstlane(sym_total);
-  XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[1] = wall_clock64();)
   uint64_t pos = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r.pos) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r.pos >> 32)) << 32);
   if (!err) {
     // Selector list (:1487-1493): n_sel unary numbers (ones closed by a zero).  Every lane takes 32 bits of a 2048-bit stretch:
@@ -222,7 +216,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
       } else { done += total; carry = (uint32_t)__builtin_amdgcn_readlane((int)t1, 63); pos += 2048; }
     }
     if (__ballot(bad != 0)) err = CJS_E_DATA_ERROR;
-    XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[2] = wall_clock64();)
     __builtin_amdgcn_wave_barrier();
     if (!err) {
       // Move-to-front over the values, the list as nibbles of one register.  A stretch of the list acts on the positions as a
@@ -256,7 +249,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
     }
     pos = endpos > r.nbits ? r.nbits : endpos;
   }
-  XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[3] = wall_clock64();)
   if (!err) {
     // Code lengths (:1500-1520): per table 5 bits, then per symbol a run of (1, direction) pairs closed by a 0.  Behind a 0 and behind
     // a direction bit stands a control bit, so in a run of ones the bits alternate control / direction from the run's first (a control
@@ -318,7 +310,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   n_sel = __builtin_amdgcn_readfirstlane(n_sel);
   const uint32_t sym_count = sym_total + 2;
   __builtin_amdgcn_wave_barrier();
-  XCLK(if (blockIdx.x == 0 && lane == 0) g_dec_clk[4] = wall_clock64();)
   if (!err) {
     // canonical tables: lane g builds table g -- a counting sort of the symbols by length, then the first codes
     if ((uint32_t)lane < group_count) {
@@ -509,7 +500,7 @@ __device__ __forceinline__ uint32_t chain_table_full(const DecShared& S, const u
 
 __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in, uint64_t n, const Cand* __restrict__ cands, uint32_t ncand, uint32_t dbuf_size,
                                                  RowTab* __restrict__ tabs, uint8_t* __restrict__ sel_all, uint32_t* __restrict__ gstart_all,
-                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0, uint32_t xb_num, uint32_t xc_num, uint32_t xd_num) {
+                                                 uint8_t* __restrict__ l0_all, BlockOut* __restrict__ outs, uint32_t row0) {
   __shared__ DecShared S;
   __shared__ uint32_t scratch[4 * CH_ARR / 2 + 12 * CH_ARR2 / 2 + CH_WORDS + 2];         // the prologue's selector values (4096 words), then the chain's arrays
   uint16_t (*A)[CH_ARR] = reinterpret_cast<uint16_t (*)[CH_ARR]>(scratch);                     // group k: next^(2^lv), lv = 0 .. 5, in four arrays (ch_slot)
@@ -542,7 +533,7 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   __threadfence_block();
   __syncthreads();
   const uint64_t t_hdr = wall_clock64();
-  if (tid == 0 && blockIdx.x == 0) { g_dec_clk[5] = t_hdr - t_k0; XCLK(g_dec_clk[1] -= t_k0; g_dec_clk[2] -= t_k0; g_dec_clk[3] -= t_k0; g_dec_clk[4] -= t_k0;) }
+  if (tid == 0 && blockIdx.x == 0) g_dec_clk[5] = t_hdr - t_k0;
   const int herr = (int)s_hdr[0];
   const uint32_t group_count = s_hdr[2], n_sel = s_hdr[3];
   const uint64_t data_bit = s_pos;
@@ -579,7 +570,6 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   if (tid < 64) { for (int a = 0; a < 4; a++) A[a][CH_SPAN + tid] = (uint16_t)(2 * (CH_SPAN + tid)); for (int a = 0; a < 12; a++) B[a][CH_T + tid] = (uint16_t)(2 * (CH_T + tid)); }
   __syncthreads();
   uint32_t ok_groups = 0;
-  XCLK(uint64_t x_steps = 0, x_two = 0, x_three = 0, x_four = 0, x_retry = 0, x_c1 = 0, x_c2 = 0, x_c3 = 0, x_c4 = 0; const uint64_t xT0 = clock64();)
   if (!herr) {
     uint64_t pos = data_bit, wbase = ~0ull;      // wbase: stream word at wbuf[0]
     // Nothing the step's first instructions need comes from memory: the tables' shortest / longest lengths sit in two registers (5 bits
@@ -617,11 +607,12 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         __syncthreads();
       }
       const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
-      XCLK(x_steps++;)
       const uint32_t i = (uint32_t)tid;
-      const ChainLater L[3] = {{B, g1, min(max(base1, lp * xb_num >> 3), CH_SPAN)},
-                               {B + 4, g2, min(max(base2, lp * xc_num >> 3), 2 * CH_SPAN - CH_T)},
-                               {B + 8, g3, min(max(base3, lp * xd_num >> 3), 2 * CH_SPAN - CH_T)}};
+      // (where the later tables start: the earliest bit the group can start at, or -- lp = the bits of the last group -- half a group in
+      // front of where groups of that length would put it, if that is more: its CH_WIN positions must hold the group's start AND end)
+      const ChainLater L[3] = {{B, g1, min(base1, CH_SPAN)},
+                               {B + 4, g2, min(max(base2, lp * 3 / 2), 2 * CH_SPAN - CH_T)},
+                               {B + 8, g3, min(max(base3, lp * 5 / 2), 2 * CH_SPAN - CH_T)}};
       uint32_t span = min(full_span, CH_WIN), e[4];
       if (g3 >= 0) chain_tables<4>(S, len12, wbuf, A, L, i, o0, g, span, span == full_span, e);
       else if (g2 >= 0) chain_tables<3>(S, len12, wbuf, A, L, i, o0, g, span, span == full_span, e);
@@ -631,7 +622,6 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]), e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[2]), e3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[3]);
       bool ok0 = e0 < span || (span == full_span && e0 == span);
       if (!ok0 && span < full_span) {              // (uniform) group k alone on its whole span
-        XCLK(x_retry++;)
         span = full_span;
         e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch_ld(A, 5, chain_table_full(S, len12, wbuf, A, i, o0, g, span))) >> 1;
         ok0 = e0 <= span;
@@ -641,19 +631,16 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
       if (!ok0) break;                             // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
       // (a later group's end is known only if those in front of it are: chain_tables)
       if (e3 < CH_WIN) {                           // four groups
-        XCLK(x_four++;)
         if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + L[0].start + e1 - data_bit); gstart[k + 3] = (uint32_t)(pos + L[1].start + e2 - data_bit); }
         ok_groups = k + 4;
         lp = L[2].start + e3 - (L[1].start + e2);
         pos += L[2].start + e3; k += 4;
       } else if (e2 < CH_WIN) {                    // three
-        XCLK(x_three++;)
         if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + L[0].start + e1 - data_bit); }
         ok_groups = k + 3;
         lp = L[1].start + e2 - (L[0].start + e1);
         pos += L[1].start + e2; k += 3;
       } else if (e1 < CH_WIN) {                    // two
-        XCLK(x_two++;)
         if (tid == 0) gstart[k + 1] = (uint32_t)(pos + e0 - data_bit);
         ok_groups = k + 2;
         lp = L[0].start + e1 - e0;
@@ -662,7 +649,6 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
-  XCLK(if (tid == 0 && blockIdx.x == 0 && !herr) { g_dec_clk[0] = x_steps | (x_two << 20) | (x_retry << 40); g_dec_clk[9] = x_three | (x_four << 32); g_dec_clk[8] = clock64() - xT0; })
   if (tid == 0) {
     T.sym_total = s_hdr[1]; T.group_count = group_count; T.n_sel = n_sel; T.err = (uint32_t)herr; T.data_bit = data_bit; T.crc = s_hdr[4]; T.orig = s_hdr[5];
     T.ngroups_ok = ok_groups; T.pad = 0; T.eob_key = ~0ull; T.err_key = ~0ull;
@@ -1427,8 +1413,7 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     uint32_t c1 = c0, rows = 0, r0 = 0;
     while (c1 < ncand && (S->cands[c1].kind != 0 || rows < nr)) { if (S->cands[c1].kind == 0) { if (!rows) r0 = S->cands[c1].pad; rows++; } c1++; }
     const uint32_t nc = c1 - c0;
-    { static const uint32_t xn = getenv("CJS_X_BNUM") ? (uint32_t)atoi(getenv("CJS_X_BNUM")) : 0u, xcn = getenv("CJS_X_CNUM") ? (uint32_t)atoi(getenv("CJS_X_CNUM")) : 12u, xdn = getenv("CJS_X_DNUM") ? (uint32_t)atoi(getenv("CJS_X_DNUM")) : 20u;
-    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0, xn, xcn, xdn); }
+    hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0);
     if (rows) hipLaunchKernelGGL(bz_group_syms, dim3(group_tiles, rows), dim3(256), 0, s, S->d_in, S->up_hi, d_tabs, d_sel, d_gstart, d_syms, sym_stride, 0u);
     hipLaunchKernelGGL(bz_sym_ops, dim3(nc), dim3(1024), 0, s, d_tabs, d_cand + c0, nc, d_syms, sym_stride, dsz, d_ops, d_opoff, ops_stride, d_nops, d_bo + c0, r0, S->up_hi * 8);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data() + c0, d_bo + c0, sizeof(BlockOut) * nc, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1468,9 +1453,8 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   S->drop(d_ops); S->drop(d_opoff); S->drop(d_l0); S->drop(d_pl); S->drop(d_nops); S->drop(d_tabs); S->drop(d_sel); S->drop(d_gstart); S->drop(d_syms);
   if (!single) { S->drop(d_ttb); S->drop(d_gdst); }
   if (getenv("CJS_DEBUG")) {
-    uint64_t clk[10];
+    uint64_t clk[8];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_dec_clk), sizeof clk) == hipSuccess) {
-      fprintf(stderr, "[cjs dec] X steps %llu four %llu three %llu two %llu retry %llu | prologue marks (10 ns) %llu %llu %llu %llu; chain cycles %llu\n", (unsigned long long)(clk[0] & 0xFFFFF), (unsigned long long)(clk[9] >> 32), (unsigned long long)(clk[9] & 0xFFFFFFFFu), (unsigned long long)((clk[0] >> 20) & 0xFFFFF), (unsigned long long)(clk[0] >> 40), (unsigned long long)clk[1], (unsigned long long)clk[2], (unsigned long long)clk[3], (unsigned long long)clk[4], (unsigned long long)clk[8]);
       fprintf(stderr, "[cjs dec] candidate 0: header + tables %.1f us, group chain %.1f us for %llu groups\n", clk[5] / 100.0, clk[6] / 100.0, (unsigned long long)clk[7]);
     }
     fprintf(stderr, "[cjs dec] share on device %d: bytes [%llu, %llu) uploaded [%llu, %llu) = %zu B, %u candidates\n", S->device, (unsigned long long)S->lo,
