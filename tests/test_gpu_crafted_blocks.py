@@ -175,6 +175,50 @@ def test_group_ends_on_a_window_edge(hip, oracle):
         assert np.array_equal(out_h, out_o), name
 
 
+def group_of_bits(bits, rng=None):
+    """50 rank symbols whose codes (20, 10 and 1 bits under lengths [20, 20, 1, 10, 20]) take exactly `bits` bits, or None"""
+    for a in range(50, -1, -1):                                  # 19 a + 9 c = bits - 50
+        rest = bits - 50 - 19 * a
+        if rest >= 0 and rest % 9 == 0 and a + rest // 9 <= 50:
+            c = rest // 9
+            g = [4] * a + [3] * c + [2] * (50 - a - c)           # symbol 4: 20 bits, 3: 10 bits, 2: 1 bit
+            if rng is not None:
+                rng.shuffle(g)
+            return g
+    return None
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_later_groups_miss_their_windows_in_every_way(hip, oracle, seed):
+    # Four groups go in one step of the decoder's chain: the first from its known start, the others over 448 positions placed by the
+    # shortest codes of the tables in front and by the length of the LAST group.  Group lengths that jump between 50 and 1000 bits
+    # put later groups in front of their positions, behind them and across their end, and the first group beyond its first attempt.
+    rng = np.random.RandomState(7000 + seed)
+    groups = []
+    while len(groups) < 240:
+        mode = rng.randint(0, 4)
+        bits = int(rng.choice([50, 59, 200, 213, 440, 447, 448, 449, 450, 600, 896, 1000])) if mode == 0 else int(rng.randint(50, 1001)) if mode == 1 \
+            else int(rng.randint(150, 300)) if mode == 2 else int(rng.randint(400, 500))
+        g = group_of_bits(bits, rng)
+        if g is not None:
+            groups.extend([g] * int(rng.randint(1, 5)))          # runs of equal lengths let the placement settle, then it jumps
+    symbols = [x for g in groups for x in g][:-1]                # (the end-of-block symbol is the last group's 50th)
+    rc_h, rc_o, out_h, out_o = decode_both(hip, oracle, symbols, used=(65, 66, 67, 68), lengths=[20, 20, 1, 10, 20, 20])
+    assert rc_h == rc_o == 0, (seed, rc_h, rc_o, hip.last_error_detail())
+    assert out_h.size == out_o.size and np.array_equal(out_h, out_o), seed
+
+
+def test_tables_whose_shortest_code_is_long(hip, oracle):
+    # 50 x the shortest code is where the next group's positions start at the earliest: with no code below 11 bits that is beyond
+    # the 448 positions of the group in front, and the third group's start is capped
+    rng = np.random.RandomState(5)
+    for lengths in ([11, 12, 11, 20, 12], [16, 20, 15, 17, 20], [9, 9, 9, 9, 9]):
+        symbols = [int(x) for x in rng.randint(2, 4, 700)]
+        rc_h, rc_o, out_h, out_o = decode_both(hip, oracle, symbols, used=(65, 66, 67), lengths=lengths)
+        assert rc_h == rc_o == 0, (lengths, rc_h, rc_o, hip.last_error_detail())
+        assert np.array_equal(out_h, out_o), lengths
+
+
 def test_missing_end_of_block_is_a_data_error(hip, oracle):
     # the selectors run out before an end-of-block symbol shows up (:1602)
     full = make_stream([2] * 120)
