@@ -571,42 +571,49 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
   __syncthreads();
   uint32_t ok_groups = 0;
   if (!herr) {
-    uint64_t pos = data_bit, wbase = ~0ull;      // wbase: stream word at wbuf[0]
-    // Nothing the step's first instructions need comes from memory: the tables' shortest / longest lengths sit in two registers (5 bits
-    // each), and lane j of every wave holds the selectors kb + j, kb + 64 + j (and, on its way, kb + 128 + j) -- written by wave 0 above,
-    // visible after the barrier.
-    uint32_t minp = 0, maxp = 0;
-    for (int t = 0; t < 6; t++) { minp |= ((uint32_t)S.minlen[t] & 31u) << (5 * t); maxp |= ((uint32_t)S.maxlen[t] & 31u) << (5 * t); }
-    minp = (uint32_t)__builtin_amdgcn_readfirstlane((int)minp); maxp = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxp);
-    uint32_t kb = 0, lp = 0;
-    uint32_t slo = (uint32_t)lane < n_sel ? sel[lane] : 0xFFu, shi = 64u + lane < n_sel ? sel[64 + lane] : 0xFFu, snx = 128u + lane < n_sel ? sel[128 + lane] : 0xFFu;
+    // Nothing the step's first instructions need comes from memory: the tables' shortest / longest lengths sit in registers (5 / 10 bits
+    // each: the longest, and 50 x the shortest), and lane j of every wave holds the selectors kb + 8 j .. kb + 8 j + 7 as nibbles (15:
+    // none) -- written by wave 0 above, visible after the barrier; 512 selectors per fill.
+    uint32_t maxp = 0; uint64_t minp = 0;
+    for (int t = 0; t < 6; t++) { minp |= (uint64_t)(GROUP_SYMS * ((uint32_t)S.minlen[t] & 31u)) << (10 * t); maxp |= ((uint32_t)S.maxlen[t] & 31u) << (5 * t); }
+    maxp = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxp);
+    minp = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)minp) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(minp >> 32)) << 32);
+    uint32_t kb = 0, sw = 0, lp = 0;
+    uint32_t rel = 0, o0 = CH_WORDS * 32;          // bits from data_bit / from the window's first word to the step's first bit (o0 past the window: fill it)
     for (uint32_t k = 0; k < n_sel;) {
-      if (k >= kb + 64) { kb += 64; slo = shi; shi = snx; snx = kb + 128 + lane < n_sel ? sel[kb + 128 + lane] : 0xFFu; }      // (uniform; k moves by <= 2)
+      if (k == 0 || k - kb >= 512 - 16) {          // (uniform) the next 512 selectors
+        kb = k & ~7u;
+        const uint32_t at = kb + 8u * (uint32_t)lane;
+        uint64_t v = ~0ull;
+        if (at < n_sel) v = *reinterpret_cast<const uint64_t*>(sel + at);                  // (the row is 8-byte aligned; bytes behind the list: masked)
+        if (at + 8 > n_sel && at < n_sel) v |= ~0ull << (8u * (n_sel - at));
+        v = (v | (v >> 4)) & 0x00FF00FF00FF00FFull; v = (v | (v >> 8)) & 0x0000FFFF0000FFFFull; v = v | (v >> 16);
+        sw = (uint32_t)v;
+      }
       const uint32_t kj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k - kb));
-      const int g = __builtin_amdgcn_readlane((int)slo, (int)kj);
-      // Up to THREE groups per step.  The tables next^1 .. next^32 of a group do not depend on where the group starts, only on its
+      const uint64_t sn = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sw, (int)((kj >> 3) + 1)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)sw, (int)(kj >> 3))) >> (4u * (kj & 7u));
+      // Up to FOUR groups per step.  The tables next^1 .. next^32 of a group do not depend on where the group starts, only on its
       // code table and on the bit positions they cover.  So beside group k's tables from its known start (A) the same threads build
       // those of group k + 1 under ITS code table over CH_WIN positions from the earliest bit it can start at (50 x the shortest code
-      // of group k's table, or a share of the last group's length if that is more) (B), and of group k + 2 likewise (C) -- in the same
-      // rounds, behind the same barriers.  When the hops on A have found where group k ends, three hops on B from that very position
-      // give the end of group k + 1, and three on C the end of group k + 2.  The span that is safe for any 50 codes (50 x the
-      // longest) is about five times what 50 codes of text take (~210 bits): the first attempt works on CH_WIN positions; a group k
-      // that leaves them (or meets a position where no code starts) is worked out again, alone, on its whole span; a later group
-      // that leaves its table's positions, or starts in front of them, simply is the first group of the next step.
-      const int g1 = k + 1 < n_sel ? (kj < 63 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 1) & 63)) : __builtin_amdgcn_readlane((int)shi, 0)) : -1;
-      const int g2 = k + 2 < n_sel ? (kj < 62 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 2) & 63)) : __builtin_amdgcn_readlane((int)shi, (int)((kj + 2) & 63))) : -1;
-      const int g3 = k + 3 < n_sel ? (kj < 61 ? __builtin_amdgcn_readlane((int)slo, (int)((kj + 3) & 63)) : __builtin_amdgcn_readlane((int)shi, (int)((kj + 3) & 63))) : -1;
+      // of group k's table), and of groups k + 2 and k + 3 likewise -- in the same rounds, behind the same barriers.  When the hops
+      // on A have found where group k ends, the later tables are looked up there, one after the other.  The span that is safe for
+      // any 50 codes (50 x the longest) is about five times what 50 codes of text take (~210 bits): the first attempt works on CH_WIN
+      // positions; a group k that leaves them (or meets a position where no code starts) is worked out again, alone, on its whole
+      // span; a later group that leaves its table's positions, or starts in front of them, simply is the first group of the next step.
+      const int g = (int)(sn & 15u);
+      const uint32_t n1 = (uint32_t)(sn >> 4) & 15u, n2 = (uint32_t)(sn >> 8) & 15u, n3 = (uint32_t)(sn >> 12) & 15u;
+      const int g1 = n1 < 6 ? (int)n1 : -1, g2 = n2 < 6 ? (int)n2 : -1, g3 = n3 < 6 ? (int)n3 : -1;
       const uint32_t full_span = min(GROUP_SYMS * ((maxp >> (5 * g)) & 31u), CH_SPAN);
-      const uint32_t base1 = GROUP_SYMS * ((minp >> (5 * g)) & 31u);        // group k + 1 starts at or behind this offset
-      const uint32_t base2 = base1 + (g1 >= 0 ? GROUP_SYMS * ((minp >> (5 * g1)) & 31u) : 0u);      // ... group k + 2 at or behind this one
-      const uint32_t base3 = base2 + (g2 >= 0 ? GROUP_SYMS * ((minp >> (5 * g2)) & 31u) : 0u);      // ... and group k + 3 here
-      if (wbase == ~0ull || (pos >> 5) < wbase || ((pos + 2 * CH_SPAN + 128) >> 5) >= wbase + CH_WORDS) {      // (uniform) refill the bit window
+      const uint32_t base1 = (uint32_t)(minp >> (10 * g)) & 1023u;                          // group k + 1 starts at or behind this offset
+      const uint32_t base2 = base1 + ((uint32_t)(minp >> (10 * min(n1, 5u))) & 1023u);       // ... group k + 2 at or behind this one
+      const uint32_t base3 = base2 + ((uint32_t)(minp >> (10 * min(n2, 5u))) & 1023u);       // ... and group k + 3 here (no group: not used)
+      if (o0 + 2 * CH_SPAN + 128 > CH_WORDS * 32) {                                         // (uniform) refill the bit window
         __syncthreads();
-        wbase = pos >> 5;
+        const uint64_t pos = data_bit + rel, wbase = pos >> 5;
         for (uint32_t i = tid; i < CH_WORDS + 2; i += CH_T) wbuf[i] = load_be32(in, n, wbase + i);
+        o0 = (uint32_t)(pos & 31u);
         __syncthreads();
       }
-      const uint32_t o0 = (uint32_t)(pos - (wbase << 5));
       const uint32_t i = (uint32_t)tid;
       // (where the later tables start: the earliest bit the group can start at, or -- lp = the bits of the last group -- half a group in
       // front of where groups of that length would put it, if that is more: its CH_WIN positions must hold the group's start AND end)
@@ -626,26 +633,28 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
         e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch_ld(A, 5, chain_table_full(S, len12, wbuf, A, i, o0, g, span))) >> 1;
         ok0 = e0 <= span;
       }
-      if (tid == 0) gstart[k] = (uint32_t)(pos - data_bit);
+      if (tid == 0) gstart[k] = rel;
       ok_groups = k + 1;
       if (!ok0) break;                             // (uniform) a code of the group is undecodable: the symbol stage reports it -- or finds the end of the block in front of it
       // (a later group's end is known only if those in front of it are: chain_tables)
+      uint32_t adv;
       if (e3 < CH_WIN) {                           // four groups
-        if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + L[0].start + e1 - data_bit); gstart[k + 3] = (uint32_t)(pos + L[1].start + e2 - data_bit); }
+        if (tid == 0) { gstart[k + 1] = rel + e0; gstart[k + 2] = rel + L[0].start + e1; gstart[k + 3] = rel + L[1].start + e2; }
         ok_groups = k + 4;
         lp = L[2].start + e3 - (L[1].start + e2);
-        pos += L[2].start + e3; k += 4;
+        adv = L[2].start + e3; k += 4;
       } else if (e2 < CH_WIN) {                    // three
-        if (tid == 0) { gstart[k + 1] = (uint32_t)(pos + e0 - data_bit); gstart[k + 2] = (uint32_t)(pos + L[0].start + e1 - data_bit); }
+        if (tid == 0) { gstart[k + 1] = rel + e0; gstart[k + 2] = rel + L[0].start + e1; }
         ok_groups = k + 3;
         lp = L[1].start + e2 - (L[0].start + e1);
-        pos += L[1].start + e2; k += 3;
+        adv = L[1].start + e2; k += 3;
       } else if (e1 < CH_WIN) {                    // two
-        if (tid == 0) gstart[k + 1] = (uint32_t)(pos + e0 - data_bit);
+        if (tid == 0) gstart[k + 1] = rel + e0;
         ok_groups = k + 2;
         lp = L[0].start + e1 - e0;
-        pos += L[0].start + e1; k += 2;
-      } else { lp = e0; pos += e0; k += 1; }                // (the second group left B's positions, met an undecodable position, or there was none: next step)
+        adv = L[0].start + e1; k += 2;
+      } else { lp = e0; adv = e0; k += 1; }        // (the second group left its table's positions, met an undecodable position, or there was none: next step)
+      rel += adv; o0 += adv;
     }
   }
   if (tid == 0 && blockIdx.x == 0) { g_dec_clk[6] = wall_clock64() - t_hdr; g_dec_clk[7] = ok_groups; }
