@@ -666,7 +666,7 @@ __global__ __launch_bounds__(CH_T) void bz_chain(const uint8_t* __restrict__ in,
 
 // one lane per group of 50 symbols; the block's tables in LDS
 __global__ __launch_bounds__(256) void bz_group_syms(const uint8_t* __restrict__ in, uint64_t n, RowTab* __restrict__ tabs, const uint8_t* __restrict__ sel_all,
-                                                     const uint32_t* __restrict__ gstart_all, uint16_t* __restrict__ syms_all, uint32_t sym_stride, uint32_t row0) {
+                                                     const uint32_t* __restrict__ gstart_all, uint16_t* __restrict__ syms_all, uint32_t sym_stride, uint32_t sym_groups, uint32_t row0) {
   __shared__ uint16_t fast[6][1024];
   __shared__ uint32_t first[6][22];
   __shared__ uint16_t cnt[6][22], start[6][22], bysym[6][260];
@@ -687,7 +687,8 @@ __global__ __launch_bounds__(256) void bz_group_syms(const uint8_t* __restrict__
   const uint32_t sym_total = T.sym_total;
   const uint64_t data_bit = T.data_bit;
   uint64_t pos = data_bit + gstart_all[(size_t)row * (MAX_SELECTORS + 1) + k];
-  uint16_t* syms = syms_all + (size_t)row * sym_stride;
+  // symbol j of group k is stored at [j][k]: the lanes of a wave (64 groups) write one line, not 64
+  uint16_t* syms = syms_all + (size_t)row * sym_groups * GROUP_SYMS + k;
   const int mx = maxlen[g];
   // a 64-bit window on the stream: a code is at most 20 bits, so the cursor crosses at most one word per symbol (one load every
   // four or five symbols of text instead of two per symbol)
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(256) void bz_group_syms(const uint8_t* __restrict__
     if (!len || idx >= sym_stride) { atomicMin(&T.err_key, (unsigned long long)idx << 32); break; }      // no code starts here (or more symbols than any block has room for)
     pos += len;
     if (sym > sym_total) { atomicMin(&T.eob_key, ((unsigned long long)idx << 32) | (unsigned long long)(uint32_t)(pos - data_bit)); break; }      // end of block (:1640)
-    syms[idx] = (uint16_t)sym;
+    syms[(size_t)j * sym_groups] = (uint16_t)sym;
   }
 }
 
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256) void bz_group_syms(const uint8_t* __restrict__
 //   rank symbols (>= 2) emit one byte each and leave as op (rank - 1, output offset); the bytes must fit the block (:1647, :1663).
 constexpr uint32_t SO_TILE = 4096;
 __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, const Cand* __restrict__ cands, uint32_t ncand, const uint16_t* __restrict__ syms_all,
-                                                   uint32_t sym_stride, uint32_t dbuf_size, uint8_t* __restrict__ ops_all, uint32_t* __restrict__ opoff_all,
+                                                   uint32_t sym_groups, uint32_t dbuf_size, uint8_t* __restrict__ ops_all, uint32_t* __restrict__ opoff_all,
                                                    uint32_t ops_stride, uint32_t* __restrict__ nops_all, BlockOut* __restrict__ outs, uint32_t row0, uint64_t nbits) {
   __shared__ uint16_t st[SO_TILE + 32];          // the tile's symbols behind the last 32 of the tile in front
   __shared__ unsigned long long sm64[16];
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, co
   const unsigned long long ek = T.eob_key, xk = T.err_key;
   if (!err && (ek == ~0ull || xk < ek)) err = CJS_E_DATA_ERROR;      // no end of block in the selectors' reach, or an undecodable code in front of it
   const uint32_t nsym = err ? 0u : (uint32_t)(ek >> 32);
-  const uint16_t* syms = syms_all + (size_t)row * sym_stride;
+  const uint16_t* syms = syms_all + (size_t)row * sym_groups * GROUP_SYMS;      // [symbol of the group][group] (bz_group_syms)
   uint8_t* ops = ops_all + (size_t)row * ops_stride;
   uint32_t* opoff = opoff_all + (size_t)row * ops_stride;
   unsigned long long off = 0;                    // bytes so far
@@ -743,8 +744,19 @@ __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, co
   if (tid < 32) st[tid] = 2;                     // in front of the first symbol: not a run
   for (uint32_t base = 0; base < nsym && !err; base += SO_TILE) {
     __syncthreads();
+    {                                             // the tile's symbols lie in 83 groups at most: along the groups, symbol by symbol of the group
+      const uint32_t k0 = base / GROUP_SYMS;
+      uint32_t at[5]; uint16_t v[5];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const uint32_t i = base + (uint32_t)tid * 4u + q; st[32 + tid * 4 + q] = i < nsym ? syms[i] : (uint16_t)2; }
+      for (int q = 0; q < 5; q++) {                // (all five loads on their way before the first is stored)
+        const uint32_t u = (uint32_t)tid + 1024u * q, j = u / 83u, k = k0 + (u - 83u * j), i = k * GROUP_SYMS + j;
+        const bool in = u < GROUP_SYMS * 83u && i >= base && i < base + SO_TILE;
+        at[q] = in ? 32u + i - base : ~0u;
+        v[q] = in && i < nsym ? syms[(size_t)j * sym_groups + k] : (uint16_t)2;
+      }
+#pragma unroll
+      for (int q = 0; q < 5; q++) if (at[q] != ~0u) st[at[q]] = v[q];
+    }
     __syncthreads();
     // position in the run: i - (index of the last rank symbol in front of i) - 1, by a max scan of (index + 1) of the rank symbols
     uint32_t lastb = 0;
@@ -1397,7 +1409,8 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   static const uint64_t budget = getenv("CJS_DEC_ROW_BYTES") ? strtoull(getenv("CJS_DEC_ROW_BYTES"), nullptr, 10) : (16ull << 30);      // (tests shrink it)
   const uint32_t sym_stride = dsz + 4096u;                              // symbols in front of the end of block: each emits a byte (but for forgotten runs), so <= dsz
   const uint32_t group_tiles = (std::min<uint32_t>(MAX_SELECTORS, sym_stride / GROUP_SYMS + 1u) + 255u) / 256u;
-  const uint64_t per_row = (uint64_t)dsz + 6ull * ops_stride + 256 + 4 + sizeof(RowTab) + MAX_SELECTORS + 4ull * (MAX_SELECTORS + 1) + 2ull * sym_stride;
+  const uint32_t sym_groups = (sym_stride + GROUP_SYMS - 1) / GROUP_SYMS;
+  const uint64_t per_row = (uint64_t)dsz + 6ull * ops_stride + 256 + 4 + sizeof(RowTab) + MAX_SELECTORS + 4ull * (MAX_SELECTORS + 1) + 2ull * sym_groups * GROUP_SYMS;
   const uint32_t nr = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nrows ? nrows : 1u, 65535u), std::max<uint64_t>(1ull, budget / per_row)));      // (<= grid.y)
   const bool single = nrows <= nr;
   uint8_t *d_ttb = nullptr, *d_ops = nullptr, *d_l0 = nullptr, *d_pl = nullptr, *d_sel = nullptr; uint32_t *d_opoff = nullptr, *d_nops = nullptr, *d_gstart = nullptr;
@@ -1412,7 +1425,7 @@ void dec_phase_a(DecJob* J, DecShare* S) {
   if (!rc) rc = S->take((void**)&d_tabs, sizeof(RowTab) * (size_t)nr);
   if (!rc) rc = S->take((void**)&d_sel, (size_t)MAX_SELECTORS * nr);
   if (!rc) rc = S->take((void**)&d_gstart, 4 * (size_t)(MAX_SELECTORS + 1) * nr);
-  if (!rc) rc = S->take((void**)&d_syms, 2 * (size_t)sym_stride * nr);
+  if (!rc) rc = S->take((void**)&d_syms, 2 * (size_t)sym_groups * GROUP_SYMS * nr);
   if (!rc && !single) rc = S->take((void**)&d_gdst, sizeof(RowDst) * (size_t)nr);
   if (rc) { S->rc = rc; return; }
   if (single) S->d_tt = d_ttb;
@@ -1423,8 +1436,8 @@ void dec_phase_a(DecJob* J, DecShare* S) {
     while (c1 < ncand && (S->cands[c1].kind != 0 || rows < nr)) { if (S->cands[c1].kind == 0) { if (!rows) r0 = S->cands[c1].pad; rows++; } c1++; }
     const uint32_t nc = c1 - c0;
     hipLaunchKernelGGL(bz_chain, dim3(nc), dim3(CH_T), 0, s, S->d_in, S->up_hi, d_cand + c0, nc, dsz, d_tabs, d_sel, d_gstart, d_l0, d_bo + c0, r0);
-    if (rows) hipLaunchKernelGGL(bz_group_syms, dim3(group_tiles, rows), dim3(256), 0, s, S->d_in, S->up_hi, d_tabs, d_sel, d_gstart, d_syms, sym_stride, 0u);
-    hipLaunchKernelGGL(bz_sym_ops, dim3(nc), dim3(1024), 0, s, d_tabs, d_cand + c0, nc, d_syms, sym_stride, dsz, d_ops, d_opoff, ops_stride, d_nops, d_bo + c0, r0, S->up_hi * 8);
+    if (rows) hipLaunchKernelGGL(bz_group_syms, dim3(group_tiles, rows), dim3(256), 0, s, S->d_in, S->up_hi, d_tabs, d_sel, d_gstart, d_syms, sym_stride, sym_groups, 0u);
+    hipLaunchKernelGGL(bz_sym_ops, dim3(nc), dim3(1024), 0, s, d_tabs, d_cand + c0, nc, d_syms, sym_groups, dsz, d_ops, d_opoff, ops_stride, d_nops, d_bo + c0, r0, S->up_hi * 8);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S->bos.data() + c0, d_bo + c0, sizeof(BlockOut) * nc, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) { S->rc = CJS_E_HIP; return; }
     uint32_t maxc = 0; uint64_t packed = 0;
