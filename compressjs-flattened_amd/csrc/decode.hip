@@ -1080,11 +1080,28 @@ __global__ __launch_bounds__(WALK_T) void ib_walk2(const uint32_t* __restrict__ 
   if (rank == 0xFFFFFFFFu || steps == 0) return;
   uint32_t cur = sidx == nspl - 1 ? start : sidx * SPL;
   // visiting order: position `rank` of the walk is slot `cur`; the loop outputs the byte of every visited slot (:1735-1736)
-  for (uint32_t q = 0; q < steps && rank + q < b.count; q++) {
-    const uint32_t e = d[cur];
-    w[sentinel ? b.count - 1 - (rank + q) : rank + q] = (uint8_t)(e & 0xFF);     // unbwtransform fills U from the end (BWTC:1161)
-    cur = e >> 8;
+  if (sentinel) {
+    for (uint32_t q = 0; q < steps && rank + q < b.count; q++) {
+      const uint32_t e = d[cur];
+      w[b.count - 1 - (rank + q)] = (uint8_t)(e & 0xFF);                         // unbwtransform fills U from the end (BWTC:1161)
+      cur = e >> 8;
+    }
+    return;
   }
+  // A lane's bytes are neighbours in w, the lanes' stretches are not: a byte per store is 64 lines per wave instruction, and the
+  // stores, not the reads, set the pace.  Whole aligned 16-byte pieces of the stretch go out as such, the words and then the bytes in
+  // front of the first and behind the last one by one (they share their pieces with the stretches of other lanes).
+  const uint32_t r1 = min(rank + steps, b.count);
+  uint32_t r = rank;
+  auto word = [&]() { uint32_t acc = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const uint32_t e = d[cur]; acc = (acc >> 8) | (e << 24); cur = e >> 8; }
+    return acc; };
+  for (; r < r1 && ((b.off + r) & 3u); r++) { const uint32_t e = d[cur]; w[r] = (uint8_t)e; cur = e >> 8; }
+  for (; r + 4 <= r1 && ((b.off + r) & 15u); r += 4) *reinterpret_cast<uint32_t*>(w + r) = word();
+  for (; r + 16 <= r1; r += 16) { uint4 q; q.x = word(); q.y = word(); q.z = word(); q.w = word(); *reinterpret_cast<uint4*>(w + r) = q; }
+  for (; r + 4 <= r1; r += 4) *reinterpret_cast<uint32_t*>(w + r) = word();
+  for (; r < r1; r++) { const uint32_t e = d[cur]; w[r] = (uint8_t)e; cur = e >> 8; }
 }
 
 // ---------------------------------------------------------------- 5. RLE1 expansion
