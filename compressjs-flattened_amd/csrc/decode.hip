@@ -355,7 +355,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
 //   bz_mtf_tiles    the move-to-front of 256 consecutive rank ops of a block, started from the identity list, by one wave
 //                   (list as bytes across the lanes, shift by wave_shr DPP): op j becomes q_j = the slot of the TILE-START
 //                   list it reads, and the tile leaves its permutation P_t.   All tiles of all blocks in parallel.
-//   bz_mtf_compose  one workgroup per block chains the tiles: start list L_(t+1)[p] = L_t[P_t[p]] (an LDS gather per tile).
+//   bz_mtf_chunk_perm + bz_mtf_compose  chain the tiles: start list L_(t+1)[p] = L_t[P_t[p]] (an LDS gather per tile), in chunks of 64 tiles.
 //   bz_mtf_emit     one thread per op: byte = L_t[q_j] at its offset, and the zero-rank run behind it (the gap to the next
 //                   op's offset) is filled with the same byte (long runs by the whole wave).
 // Same results as the reference loop (:1597-1670): every way it can fail there is DATA_ERROR, so a block is good iff its first
@@ -849,17 +849,48 @@ __global__ __launch_bounds__(256) void bz_mtf_tiles(uint8_t* __restrict__ ops_al
   reinterpret_cast<uint32_t*>(pl_all + ((size_t)row * tiles_per_row + t) * MT_TILE)[lane] = L;
 }
 
-__global__ __launch_bounds__(256) void bz_mtf_compose(const uint32_t* __restrict__ nops_all, const uint8_t* __restrict__ l0_all,
-                                                      uint8_t* __restrict__ pl_all, uint32_t tiles_per_row) {
+// The tiles of a row are chained in chunks of MC_TILES: first every chunk's product of permutations (from the identity), then -- chunk
+// by chunk again, all at once -- the start list of the chunk (the row's initial list through the products of the chunks in front) and
+// from it the start list of each of its tiles.  (One workgroup walking a row's ~1,300 tiles, two barriers each, took 0.48 ms per 100 MB.)
+constexpr uint32_t MC_TILES = 64;
+__global__ __launch_bounds__(256) void bz_mtf_chunk_perm(const uint32_t* __restrict__ nops_all, const uint8_t* __restrict__ pl_all, uint32_t tiles_per_row,
+                                                         uint8_t* __restrict__ cperm_all, size_t cperm_stride) {
   __shared__ uint8_t sl[256];
-  const uint32_t row = blockIdx.x, p = threadIdx.x;
-  const uint32_t nops = nops_all[row];
-  const uint32_t nt = (nops + MT_TILE - 1) / MT_TILE;
+  const uint32_t row = blockIdx.y, p = threadIdx.x;
+  const uint32_t nt = (nops_all[row] + MT_TILE - 1) / MT_TILE, t0 = blockIdx.x * MC_TILES, t1 = min(t0 + MC_TILES, nt);
+  if (t0 >= nt) return;
+  const uint8_t* pl = pl_all + (size_t)row * tiles_per_row * MT_TILE;
+  uint8_t cur = (uint8_t)p, idx = pl[(size_t)t0 * MT_TILE + p];
+  for (uint32_t t = t0; t < t1; t++) {
+    const uint8_t nidx = t + 1 < t1 ? pl[(size_t)(t + 1) * MT_TILE + p] : 0;      // the next permutation travels while this one is applied
+    sl[p] = cur;
+    __syncthreads();
+    cur = sl[idx];
+    __syncthreads();
+    idx = nidx;
+  }
+  cperm_all[(size_t)row * cperm_stride + (size_t)blockIdx.x * 256 + p] = cur;
+}
+__global__ __launch_bounds__(256) void bz_mtf_compose(const uint32_t* __restrict__ nops_all, const uint8_t* __restrict__ l0_all, uint8_t* __restrict__ pl_all,
+                                                      uint32_t tiles_per_row, const uint8_t* __restrict__ cperm_all, size_t cperm_stride) {
+  __shared__ uint8_t sl[256];
+  const uint32_t row = blockIdx.y, p = threadIdx.x;
+  const uint32_t nt = (nops_all[row] + MT_TILE - 1) / MT_TILE, t0 = blockIdx.x * MC_TILES, t1 = min(t0 + MC_TILES, nt);
+  if (t0 >= nt) return;
   uint8_t* pl = pl_all + (size_t)row * tiles_per_row * MT_TILE;
+  const uint8_t* cp = cperm_all + (size_t)row * cperm_stride;
   uint8_t cur = l0_all[(size_t)row * 256 + p];
-  uint8_t idx = nt ? pl[p] : 0;
-  for (uint32_t t = 0; t < nt; t++) {
-    const uint8_t nidx = t + 1 < nt ? pl[(size_t)(t + 1) * MT_TILE + p] : 0;      // the next permutation travels while this one is applied
+  uint8_t idx = blockIdx.x ? cp[p] : pl[(size_t)t0 * MT_TILE + p];
+  for (uint32_t c = 0; c < blockIdx.x; c++) {                                      // the chunks in front
+    const uint8_t nidx = c + 1 < blockIdx.x ? cp[(size_t)(c + 1) * 256 + p] : pl[(size_t)t0 * MT_TILE + p];
+    sl[p] = cur;
+    __syncthreads();
+    cur = sl[idx];
+    __syncthreads();
+    idx = nidx;
+  }
+  for (uint32_t t = t0; t < t1; t++) {
+    const uint8_t nidx = t + 1 < t1 ? pl[(size_t)(t + 1) * MT_TILE + p] : 0;
     sl[p] = cur;
     __syncthreads();
     pl[(size_t)t * MT_TILE + p] = cur;                                            // start list of tile t, in place of its permutation
@@ -1465,7 +1496,12 @@ void dec_phase_a(DecJob* J, DecShare* S) {
       const uint32_t slab = std::min<uint32_t>(65535u, std::max<uint32_t>(1u, (1u << 23) / tiles_used));
       for (uint32_t q0 = 0; q0 < rows; q0 += slab)
         hipLaunchKernelGGL(bz_mtf_tiles, dim3((tiles_used + 3u) / 4u, std::min(slab, rows - q0)), dim3(256), 0, s, d_ops, ops_stride, d_nops, d_pl, tiles_per_row, q0);
-      hipLaunchKernelGGL(bz_mtf_compose, dim3(rows), dim3(256), 0, s, d_nops, d_l0, d_pl, tiles_per_row);
+      {                                                                // (the symbols are spent: their rows hold the chunks' products)
+        const uint32_t chunks = (tiles_used + MC_TILES - 1) / MC_TILES;
+        const size_t cstride = 2 * (size_t)sym_groups * GROUP_SYMS;
+        hipLaunchKernelGGL(bz_mtf_chunk_perm, dim3(chunks, rows), dim3(256), 0, s, d_nops, d_pl, tiles_per_row, reinterpret_cast<uint8_t*>(d_syms), cstride);
+        hipLaunchKernelGGL(bz_mtf_compose, dim3(chunks, rows), dim3(256), 0, s, d_nops, d_l0, d_pl, tiles_per_row, reinterpret_cast<const uint8_t*>(d_syms), cstride);
+      }
       for (uint32_t q0 = 0; q0 < rows; q0 += slab)
         hipLaunchKernelGGL(bz_mtf_emit, dim3(tiles_used, std::min(slab, rows - q0)), dim3(256), 0, s, d_ops, d_opoff, ops_stride, d_nops, d_l0, d_pl, tiles_per_row, q0, d_ttb, dsz);
       if (hipGetLastError() != hipSuccess) { S->rc = CJS_E_HIP; return; }
