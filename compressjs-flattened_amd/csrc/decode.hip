@@ -31,6 +31,8 @@ namespace cjs {
 int select_device(const cjs_opts* opts);
 template <typename K>
 int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit);
+template <typename K>
+int radix_pass_segments_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t nseg, uint32_t stride, int lo_bit, int hi_bit);
 int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, const uint32_t* d_nblocks, uint32_t count, uint32_t max_segs,
                uint32_t* d_seg_crc, uint32_t* d_crc_out);
 }
@@ -950,20 +952,24 @@ struct IbBlock {            // per valid block, in stream order
   uint64_t tt;              // device address of the block's decoded BWT bytes
   uint32_t count;           // n
   uint32_t orig;
-  uint32_t off;             // element offset of the block in the concatenated arrays
+  uint32_t off;             // element offset of the block in the concatenated sort / LF arrays
+  uint32_t woff;            // byte offset of the block in the walk's output (w)
   uint64_t out_off;         // byte offset of the block in the final output
   uint32_t out_len;
   uint32_t crc;
 };
 
 // keys (block << 8 | byte), vals = i
-__global__ __launch_bounds__(256) void ib_make_keys(const IbBlock* __restrict__ blocks, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+// `stride` > 0: every block owns `stride` slots (one segment of a segmented sort each); the slots behind its bytes hold the largest
+// digit, which the stable sort leaves behind everything real.
+__global__ __launch_bounds__(256) void ib_make_keys(const IbBlock* __restrict__ blocks, uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t stride) {
   const IbBlock b = blocks[blockIdx.y];
   const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < b.count; i += gridDim.x * 256) {
     key[b.off + i] = ((uint32_t)blockIdx.y << 8) | tt[i];
     val[b.off + i] = i;
   }
+  for (uint32_t i = b.count + blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) { key[b.off + i] = 0xFFu; val[b.off + i] = 0; }
 }
 // after the stable sort: slot j of the block holds (T[j] << 8) | tt[j] == the reference's dbuf (:1686-1690):
 // the pointer comes from the sorted order, the low byte is the j-th DECODED byte (not the sorted one)
@@ -1092,7 +1098,7 @@ __global__ __launch_bounds__(256) void ib_periodic_fill(const IbBlock* __restric
   const IbBlock b = blocks[blockIdx.y];
   const uint32_t L = (uint32_t)cyc[blockIdx.y];
   if (L == 0 || L >= b.count) return;
-  uint8_t* w = wbuf + b.off;
+  uint8_t* w = wbuf + b.woff;
   for (uint32_t r = L + blockIdx.x * 256 + threadIdx.x; r < b.count; r += gridDim.x * 256) w[r] = w[r % L];
 }
 // second walk: write the pre-RLE1 byte sequence w[0..n) of each block (w[r] = byte of the (r+1)-th visited slot)
@@ -1103,7 +1109,7 @@ __global__ __launch_bounds__(WALK_T) void ib_walk2(const uint32_t* __restrict__ 
   if (!walk_item(nblocks, cpb, blk, sidx)) return;
   const IbBlock b = blocks[blk];
   const uint32_t* d = dbuf + b.off;
-  uint8_t* w = wbuf + b.off;
+  uint8_t* w = wbuf + b.woff;
   const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;
   if (sidx >= nspl) return;
   const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;
@@ -1128,8 +1134,8 @@ __global__ __launch_bounds__(WALK_T) void ib_walk2(const uint32_t* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; t++) { const uint32_t e = d[cur]; acc = (acc >> 8) | (e << 24); cur = e >> 8; }
     return acc; };
-  for (; r < r1 && ((b.off + r) & 3u); r++) { const uint32_t e = d[cur]; w[r] = (uint8_t)e; cur = e >> 8; }
-  for (; r + 4 <= r1 && ((b.off + r) & 15u); r += 4) *reinterpret_cast<uint32_t*>(w + r) = word();
+  for (; r < r1 && ((b.woff + r) & 3u); r++) { const uint32_t e = d[cur]; w[r] = (uint8_t)e; cur = e >> 8; }
+  for (; r + 4 <= r1 && ((b.woff + r) & 15u); r += 4) *reinterpret_cast<uint32_t*>(w + r) = word();
   for (; r + 16 <= r1; r += 16) { uint4 q; q.x = word(); q.y = word(); q.z = word(); q.w = word(); *reinterpret_cast<uint4*>(w + r) = q; }
   for (; r + 4 <= r1; r += 4) *reinterpret_cast<uint32_t*>(w + r) = word();
   for (; r < r1; r++) { const uint32_t e = d[cur]; w[r] = (uint8_t)e; cur = e >> 8; }
@@ -1239,7 +1245,7 @@ __global__ __launch_bounds__(1024) void unrle1_count(const uint8_t* __restrict__
   __shared__ uint32_t fnarr[1024];
   __shared__ uint32_t posarr[1024];
   const IbBlock b = blocks[blockIdx.x];
-  const uint8_t* w = wbuf + b.off;
+  const uint8_t* w = wbuf + b.woff;
   RleCarry cy{0u, 0u, 0u, 0u};
   uint32_t t = 0;
   for (uint32_t base = 0; base < b.count; base += UR_TILE, t++) {
@@ -1258,7 +1264,7 @@ __global__ __launch_bounds__(1024) void unrle1_write(const uint8_t* __restrict__
   const uint32_t base = blockIdx.x * UR_TILE;
   if (base >= b.count) return;
   RleCarry cy = carry[(size_t)blockIdx.y * tiles_per_block + blockIdx.x];
-  unrle1_tile<true>(wbuf + b.off, b.count, base, cy, out + b.out_off, sm, fnarr, posarr);
+  unrle1_tile<true>(wbuf + b.woff, b.count, base, cy, out + b.out_off, sm, fnarr, posarr);
 }
 
 __global__ void ib_make_crc_ranges(const IbBlock* __restrict__ blocks, uint32_t nblocks, RleBlock* __restrict__ ranges, uint32_t* __restrict__ nb_dev) {
@@ -1281,7 +1287,7 @@ static int ibwt_sentinel_slab(hipStream_t s, const uint8_t* d_T, uint32_t max_le
   for (uint32_t k = 0; k < nb; k++) {
     IbBlock& b = chain[k];
     b.tt = (uint64_t)(uintptr_t)(d_T + M64);
-    b.count = lens[k]; b.orig = pidx[k]; b.off = (uint32_t)M64; b.out_off = M64; b.out_len = lens[k]; b.crc = 0;
+    b.count = lens[k]; b.orig = pidx[k]; b.off = b.woff = (uint32_t)M64; b.out_off = M64; b.out_len = lens[k]; b.crc = 0;
     M64 += lens[k];
   }
   if (M64 >= 0xFFFFF000ull) return CJS_E_UNSUPPORTED;
@@ -1303,7 +1309,7 @@ static int ibwt_sentinel_slab(hipStream_t s, const uint8_t* d_T, uint32_t max_le
   sw.hist_tiles = (uint32_t)T; sw.bintot_segs = 1;
   if (!rc && hipMemcpyAsync(d_blocks, chain.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
   if (rc) { cleanup(); return rc; }
-  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_blocks, d_key0, d_val0);
+  hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, d_blocks, d_key0, d_val0, 0u);
   int cur = 0;
   int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
   rc = radix_passes_public<uint32_t>(s, sw, d_key0, d_val0, d_key1, d_val1, cur, M, 0, kbits);
@@ -1573,25 +1579,38 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     const uint32_t nb = (uint32_t)(b1 - b0);
     const uint64_t e0 = S->ebase[b0 - S->c0], M64 = S->ebase[b1 - S->c0] - e0;
     if (M64 >= 0xFFFFF000ull) { rc = CJS_E_UNSUPPORTED; break; }     // a single block list beyond the batch limit cannot happen (count <= 900000)
-    const uint32_t M = (uint32_t)M64;
-    for (size_t k = b0; k < b1; k++) J->chain[k].off = (uint32_t)(S->ebase[k - S->c0] - e0);
+    // Blocks of (nearly) one size -- a stream's are, but for its last -- get a slot range of that size each and ONE pass of the sort,
+    // segment by segment; otherwise the block number is sorted on too (one or two more passes over everything).
+    uint32_t maxc = 0;
+    for (size_t k = b0; k < b1; k++) maxc = std::max(maxc, J->chain[k].count);
+    const uint32_t seg_stride = (maxc + 3u) & ~3u;
+    const bool strided = (uint64_t)nb * seg_stride <= M64 + M64 / 4 && (uint64_t)nb * seg_stride < 0xFFFFF000ull;
+    const uint32_t M = strided ? nb * seg_stride : (uint32_t)M64;
+    for (size_t k = b0; k < b1; k++) {
+      J->chain[k].woff = (uint32_t)(S->ebase[k - S->c0] - e0);
+      J->chain[k].off = strided ? (uint32_t)(k - b0) * seg_stride : J->chain[k].woff;
+    }
     IbScratch q;
     rc = S->take((void**)&q.d_blocks, sizeof(IbBlock) * nb);
     if (!rc) rc = S->take((void**)&q.key0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.key1, 4 * (size_t)M + 64);
     if (!rc) rc = S->take((void**)&q.val0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.val1, 4 * (size_t)M + 64);
     if (!rc) rc = S->take((void**)&q.snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.ssteps, 4 * (size_t)nb * spl_stride);
     if (!rc) rc = S->take((void**)&q.srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.d_err, 4 * (size_t)nb);
-    const size_t T = ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
-    if (!rc) rc = S->take((void**)&q.sw.hist, BwtWork::hist_words(T) * 4); if (!rc) rc = S->take((void**)&q.sw.bintot, 256 * 4);
-    q.sw.hist_tiles = (uint32_t)T; q.sw.bintot_segs = 1;
+    const uint32_t tps = (seg_stride + RS_TILE - 1) / RS_TILE;
+    const size_t T = strided ? (size_t)nb * tps + 1 : ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
+    if (!rc) rc = S->take((void**)&q.sw.hist, BwtWork::hist_words(T) * 4); if (!rc) rc = S->take((void**)&q.sw.bintot, 256 * 4 * (size_t)(strided ? nb : 1u));
+    q.sw.hist_tiles = (uint32_t)T; q.sw.bintot_segs = strided ? nb : 1u;
     if (!rc && hipMemcpyAsync(q.d_blocks, J->chain.data() + b0, sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
     if (!rc && hipMemsetAsync(q.d_err, 0, 4 * (size_t)nb, s) != hipSuccess) rc = CJS_E_HIP;
     if (rc) break;
     uint8_t* d_wb = S->d_w + e0;
-    hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, q.d_blocks, q.key0, q.val0);
+    hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, q.d_blocks, q.key0, q.val0, strided ? seg_stride : 0u);
     int cur = 0;
-    int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
-    rc = radix_passes_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, M, 0, kbits);
+    if (strided) rc = radix_pass_segments_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, nb, seg_stride, 0, 8);
+    else {
+      int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
+      rc = radix_passes_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, M, 0, kbits);
+    }
     if (rc) break;
     uint32_t* sval = cur ? q.val1 : q.val0;
     uint32_t* d_dbuf = cur ? q.key0 : q.key1;                      // the buffer the sort is not sitting in
@@ -1629,7 +1648,7 @@ void dec_phase_c(DecJob* J, DecShare* S) {
     std::vector<IbBlock> blk(J->chain.begin() + (long)b0, J->chain.begin() + (long)b1);
     uint32_t need_segs = 1;
     for (uint32_t k = 0; k < nb; k++) {
-      blk[k].off = (uint32_t)(S->ebase[b0 + k - S->c0] - e0);
+      blk[k].off = blk[k].woff = (uint32_t)(S->ebase[b0 + k - S->c0] - e0);
       blk[k].out_off = J->out_off[b0 + k] - o0;                   // inside the batch's output buffer
       const uint32_t sg = (uint32_t)((blk[k].out_len + 16383) / 16384 + 1);
       if (sg > need_segs) need_segs = sg;
@@ -1755,7 +1774,7 @@ static int bunzip_core(const uint8_t* in, size_t n, int multistream, int mode, u
     if (bo.err != CJS_E_OBSOLETE_INPUT && bo.orig > dbuf_size) { set_detail("initial position out of bounds"); return CJS_E_DATA_ERROR; }   // :1449-1450
     if (bo.err) return bo.err;
     if (bo.count > dbuf_size) return CJS_E_DATA_ERROR;             // decoded with the largest level's limit: this stream's is lower (:1647,1663)
-    IbBlock ib; ib.tt = S.tt_ptr[clocal[(size_t)ci]]; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
+    IbBlock ib; ib.tt = S.tt_ptr[clocal[(size_t)ci]]; ib.count = bo.count; ib.orig = bo.orig; ib.off = 0; ib.woff = 0; ib.out_off = 0; ib.out_len = 0; ib.crc = bo.crc;
     J.chain.push_back(ib); J.chain_bits.push_back(bitpos); chain_share.push_back(cshare[(size_t)ci]);
     return 0;
   };
