@@ -1151,16 +1151,40 @@ __device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) { 
 }
 // One tile (UR_TILE = 1024 threads x UR_BPT bytes) of a block by one workgroup.  Carried from the tiles in front: start of the current stretch,
 // c0 of the current stretch, output bytes so far; WRITE: the bytes go out, else they are only counted.
+constexpr int UR_BPT_C = 16;
+// A thread's UR_BPT = 16 bytes w[p0 .. p0 + 16) and the byte in front of them (0 at the block's first byte), bytes behind the block's
+// end as 0.  The address has any alignment (the same for the whole workgroup): two aligned 16-byte loads and a funnel shift (a byte
+// per load was 17 instructions of 16 lines each; the walk's output buffer has 64 bytes of slack behind its last block).
+__device__ __forceinline__ void ur_load(const uint8_t* __restrict__ w, uint32_t n, uint32_t p0, uint8_t (&c)[UR_BPT_C + 1]) {
+  const uintptr_t A = (uintptr_t)(w + p0);
+  const uint4* q = reinterpret_cast<const uint4*>(A & ~(uintptr_t)15);
+  const uint32_t r = 8u * ((uint32_t)A & 3u);
+  uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+  if (p0 < n) { lo = q[0]; hi = q[1]; }             // (at most 31 bytes behind the block's end)
+  uint32_t d[4];
+  switch (((uint32_t)A >> 2) & 3u) {              // (uniform)
+    case 0: d[0] = __funnelshift_r(lo.x, lo.y, r); d[1] = __funnelshift_r(lo.y, lo.z, r); d[2] = __funnelshift_r(lo.z, lo.w, r); d[3] = __funnelshift_r(lo.w, hi.x, r); break;
+    case 1: d[0] = __funnelshift_r(lo.y, lo.z, r); d[1] = __funnelshift_r(lo.z, lo.w, r); d[2] = __funnelshift_r(lo.w, hi.x, r); d[3] = __funnelshift_r(hi.x, hi.y, r); break;
+    case 2: d[0] = __funnelshift_r(lo.z, lo.w, r); d[1] = __funnelshift_r(lo.w, hi.x, r); d[2] = __funnelshift_r(hi.x, hi.y, r); d[3] = __funnelshift_r(hi.y, hi.z, r); break;
+    default: d[0] = __funnelshift_r(lo.w, hi.x, r); d[1] = __funnelshift_r(hi.x, hi.y, r); d[2] = __funnelshift_r(hi.y, hi.z, r); d[3] = __funnelshift_r(hi.z, hi.w, r); break;
+  }
+#pragma unroll
+  for (int j = 0; j < UR_BPT_C; j++) c[j + 1] = p0 + j < n ? (uint8_t)(d[j >> 2] >> (8 * (j & 3))) : (uint8_t)0;
+  uint32_t prev = (uint32_t)__shfl_up((int)(d[3] >> 24), 1, 64);                 // the lane in front holds the byte in front (beyond n: never looked at)
+  if (lane_id() == 0) prev = (p0 > 0 && p0 - 1 < n) ? w[p0 - 1] : 0u;
+  c[0] = (uint8_t)prev;
+}
 struct RleCarry { uint32_t cur_start, cur_c0, out_base, pad; };
-constexpr int UR_BPT = 16;                    // bytes per thread: the ten-step function scan over the 1024 threads is most of a tile, whatever the bytes per thread (4 bytes: 1.05 ms per 100 MB for the length pass)
+static_assert(UR_BPT_C == 16, "ur_load");
+constexpr int UR_BPT = UR_BPT_C;                    // bytes per thread: the ten-step function scan over the 1024 threads is most of a tile, whatever the bytes per thread (4 bytes: 1.05 ms per 100 MB for the length pass)
 constexpr uint32_t UR_TILE = 1024 * UR_BPT;
+constexpr uint32_t UR_STAGE = 24 * 1024;      // bytes of a tile's output put together in LDS (a tile of plain text makes UR_TILE and a few)
 template <bool WRITE>
 __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint32_t n, uint32_t base, RleCarry& cy, uint8_t* __restrict__ o,
-                                            uint32_t* sm, uint32_t* fnarr, uint32_t* posarr) {
+                                            uint32_t* sm, uint32_t* fnarr, uint32_t* posarr, uint8_t* stage) {
   const uint32_t p0 = base + threadIdx.x * UR_BPT;
-  uint8_t c[UR_BPT + 1]; c[0] = (p0 > 0 && p0 - 1 < n) ? w[p0 - 1] : 0;
-#pragma unroll
-  for (int j = 0; j < UR_BPT; j++) c[j + 1] = p0 + j < n ? w[p0 + j] : 0;
+  uint8_t c[UR_BPT + 1];
+  ur_load(w, n, p0, c);
   // stretch boundaries inside my positions
   uint32_t bmask = 0, lastb = 0;
 #pragma unroll
@@ -1227,32 +1251,171 @@ __device__ __forceinline__ void unrle1_tile(const uint8_t* __restrict__ w, uint3
   uint32_t tot;
   uint32_t off = cy.out_base + block_excl_sum<1024>(cnt, sm, tot);
   if (WRITE) {
+    // The tile's bytes are one stretch of the output, a thread's a few of them at an odd address: they are put together in LDS (at the
+    // stretch's own alignment) and leave as aligned 16-byte pieces; a tile of long runs that does not fit goes out byte by byte.
+    uint8_t* dst = o + cy.out_base;
+    const uint32_t al = (uint32_t)((uintptr_t)dst & 15u);
+    const bool staged = tot <= UR_STAGE;
+    uint32_t rel = off - cy.out_base;
+    if (staged) {                                  // (uniform)
 #pragma unroll
-    for (int j = 0; j < UR_BPT; j++) {
-      const uint32_t p = p0 + j;
-      if (p < n) {
-        if ((is_cnt >> j) & 1u) { const uint32_t k = c[j + 1]; const uint8_t v = c[j]; for (uint32_t q = 0; q < k; q++) o[off + q] = v; off += k; }
-        else o[off++] = c[j + 1];
+      for (int j = 0; j < UR_BPT; j++) {
+        if (p0 + j < n) {
+          if ((is_cnt >> j) & 1u) { const uint32_t k = c[j + 1]; const uint8_t v = c[j]; for (uint32_t q = 0; q < k; q++) stage[al + rel + q] = v; rel += k; }
+          else stage[al + rel++] = c[j + 1];
+        }
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < UR_BPT; j++) {
+        if (p0 + j < n) {
+          if ((is_cnt >> j) & 1u) { const uint32_t k = c[j + 1]; const uint8_t v = c[j]; for (uint32_t q = 0; q < k; q++) dst[rel + q] = v; rel += k; }
+          else dst[rel++] = c[j + 1];
+        }
+      }
+    }
+    if (staged) {
+      __syncthreads();
+      const uint32_t lead = min((16u - al) & 15u, tot), body = (tot - lead) >> 4, tail = lead + (body << 4);
+      if (threadIdx.x < lead) dst[threadIdx.x] = stage[al + threadIdx.x];
+      for (uint32_t i = threadIdx.x; i < body; i += 1024) reinterpret_cast<uint4*>(dst + lead)[i] = reinterpret_cast<const uint4*>(stage + al + lead)[i];
+      if (threadIdx.x < tot - tail) dst[tail + threadIdx.x] = stage[al + tail + threadIdx.x];
     }
   }
   cy.out_base += tot;
   if (tile_last) { cy.cur_c0 = fn_apply(fall, cy.cur_c0); cy.cur_start = tile_last - 1; }
 }
-// length pass: one workgroup per block, tiles front to back; leaves the state carried INTO every tile for the write pass
-__global__ __launch_bounds__(1024) void unrle1_count(const uint8_t* __restrict__ wbuf, IbBlock* __restrict__ blocks, RleCarry* __restrict__ carry, uint32_t tiles_per_block) {
+// The length pass, every tile of every block at once, in three launches (one workgroup per block walking its tiles front to back took
+// 0.63 ms per 100 MB).  A tile depends on what lies in front of it through three things only: where the stretch that runs into it
+// started (the last boundary in front), the carried bit c0 of that stretch, and the bytes out so far.  So: (1) every tile's last
+// boundary; (2) with the last boundary in front of it, every tile's function on c0 and its byte count for BOTH values of c0;
+// (3) per block, one wave chains the functions and sums the counts: the state carried INTO every tile, for the write pass.
+// The RleCarry slot of a tile holds the intermediate values: pad = last boundary + 1 (0: none), cur_c0 = function, cur_start /
+// out_base = bytes for c0 = 0 / 1.
+__global__ __launch_bounds__(1024) void unrle1_bounds(const uint8_t* __restrict__ wbuf, const IbBlock* __restrict__ blocks, RleCarry* __restrict__ carry, uint32_t tiles_per_block) {
   __shared__ uint32_t sm[16];
-  __shared__ uint32_t fnarr[1024];
-  __shared__ uint32_t posarr[1024];
-  const IbBlock b = blocks[blockIdx.x];
+  const IbBlock b = blocks[blockIdx.y];
+  const uint32_t base = blockIdx.x * UR_TILE;
+  if (base >= b.count) return;
   const uint8_t* w = wbuf + b.woff;
-  RleCarry cy{0u, 0u, 0u, 0u};
-  uint32_t t = 0;
-  for (uint32_t base = 0; base < b.count; base += UR_TILE, t++) {
-    if (threadIdx.x == 0 && t < tiles_per_block) carry[(size_t)blockIdx.x * tiles_per_block + t] = cy;
-    unrle1_tile<false>(w, b.count, base, cy, nullptr, sm, fnarr, posarr);
+  const uint32_t p0 = base + threadIdx.x * UR_BPT;
+  uint8_t c[UR_BPT + 1];
+  ur_load(w, b.count, p0, c);
+  uint32_t lastb = 0;
+#pragma unroll
+  for (int j = 0; j < UR_BPT; j++) { const uint32_t p = p0 + j; if (p < b.count && p > 0 && c[j + 1] != c[j]) lastb = p + 1; }
+  const uint32_t im = block_incl_max<1024>(lastb, sm);
+  if (threadIdx.x == 1023) carry[(size_t)blockIdx.y * tiles_per_block + blockIdx.x].pad = im;
+}
+__global__ __launch_bounds__(1024) void unrle1_sums(const uint8_t* __restrict__ wbuf, const IbBlock* __restrict__ blocks, RleCarry* __restrict__ carry, uint32_t tiles_per_block) {
+  __shared__ unsigned long long sm64[16];
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t fnarr[32];
+  __shared__ uint32_t posarr[1024];
+  __shared__ uint32_t s_start;
+  const IbBlock b = blocks[blockIdx.y];
+  const uint32_t base = blockIdx.x * UR_TILE, n = b.count;
+  if (base >= n) return;
+  const uint8_t* w = wbuf + b.woff;
+  RleCarry* row = carry + (size_t)blockIdx.y * tiles_per_block;
+  if (threadIdx.x == 0) {                         // the last boundary in front of the tile: as a rule in the tile in front
+    uint32_t st = 0;
+    for (uint32_t t = blockIdx.x; t-- > 0;) { const uint32_t lb = row[t].pad; if (lb) { st = lb - 1; break; } }
+    s_start = st;
   }
-  if (threadIdx.x == 0) blocks[blockIdx.x].out_len = cy.out_base;
+  const uint32_t p0 = base + threadIdx.x * UR_BPT;
+  uint8_t c[UR_BPT + 1];
+  ur_load(w, n, p0, c);
+  uint32_t bmask = 0, lastb = 0;
+#pragma unroll
+  for (int j = 0; j < UR_BPT; j++) { const uint32_t p = p0 + j; if (p < n && p > 0 && c[j + 1] != c[j]) { bmask |= 1u << j; lastb = p + 1; } }
+  const uint32_t im = block_incl_max<1024>(lastb, sm);
+  posarr[threadIdx.x] = im;
+  __syncthreads();
+  const uint32_t exb = threadIdx.x ? posarr[threadIdx.x - 1] : 0u;
+  const uint32_t cur_start = s_start;
+  uint32_t f = 2u;   // identity
+  {
+    uint32_t ps = exb ? exb - 1 : cur_start;
+#pragma unroll
+    for (int j = 0; j < UR_BPT; j++) if ((bmask >> j) & 1u) { const uint32_t p = p0 + j; f = fn_compose(f, stretch_fn(p - ps)); ps = p; }
+  }
+  uint32_t incl = f;
+  {
+    const int lane = lane_id(), wv = wave_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t other = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl = fn_compose(other, incl);
+    }
+    if (lane == 63) fnarr[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+      uint32_t t = lane < 16 ? fnarr[lane] : 2u;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t other = (uint32_t)__shfl_up((int)t, d, 64);
+        if (lane >= d) t = fn_compose(other, t);
+      }
+      if (lane < 16) fnarr[16 + lane] = t;
+    }
+    __syncthreads();
+  }
+  const uint32_t wprefix = wave_id() ? fnarr[16 + wave_id() - 1] : 2u;
+  uint32_t fex = (uint32_t)__shfl_up((int)incl, 1, 64);
+  fex = lane_id() ? fn_compose(wprefix, fex) : wprefix;
+  const uint32_t fall = fnarr[16 + 15];
+  unsigned long long both = 0;                    // bytes out of my positions for c0 = 0 (low half) and c0 = 1 (high half) at the tile's start
+#pragma unroll
+  for (int v = 0; v < 2; v++) {
+    uint32_t c0 = fn_apply(fex, (uint32_t)v), ps = exb ? exb - 1 : cur_start, cnt = 0;
+#pragma unroll
+    for (int j = 0; j < UR_BPT; j++) {
+      const uint32_t p = p0 + j;
+      if (p < n) {
+        if ((bmask >> j) & 1u) { c0 = fn_apply(stretch_fn(p - ps), c0); ps = p; }
+        const uint32_t q = ps + c0;
+        const uint32_t rel = p >= q ? p - q : 0u;
+        const uint32_t count_byte = ((p == ps) & c0) | ((p >= q) & ((rel % 5u) == 4u));
+        cnt += count_byte ? (uint32_t)c[j + 1] : 1u;
+      }
+    }
+    both |= (unsigned long long)cnt << (32 * v);
+  }
+  unsigned long long tot;
+  block_excl_sum<1024>(both, sm64, tot);
+  if (threadIdx.x == 0) { RleCarry& e = row[blockIdx.x]; e.cur_c0 = fall; e.cur_start = (uint32_t)tot; e.out_base = (uint32_t)(tot >> 32); }
+}
+__global__ __launch_bounds__(64) void unrle1_carries(IbBlock* __restrict__ blocks, RleCarry* __restrict__ carry, uint32_t tiles_per_block) {
+  const IbBlock b = blocks[blockIdx.x];
+  RleCarry* row = carry + (size_t)blockIdx.x * tiles_per_block;
+  const uint32_t nt = (b.count + UR_TILE - 1) / UR_TILE;
+  const int lane = lane_id();
+  uint32_t prevb = 0, c0 = 0, out = 0;            // last boundary + 1 / carried bit / bytes out in front of the chunk of 64 tiles
+  for (uint32_t t0 = 0; t0 < nt; t0 += 64) {
+    const uint32_t t = t0 + lane;
+    RleCarry e{0u, 2u, 0u, 0u};                   // (behind the last tile: no bytes, the identity, no boundary)
+    if (t < nt) e = row[t];
+    const uint32_t im = wave_incl_max(e.pad);
+    uint32_t exm = (uint32_t)__shfl_up((int)im, 1, 64); if (lane == 0) exm = 0;
+    exm = exm > prevb ? exm : prevb;
+    uint32_t incl = e.cur_c0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t other = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl = fn_compose(other, incl);
+    }
+    uint32_t fex = (uint32_t)__shfl_up((int)incl, 1, 64); if (lane == 0) fex = 2u;
+    const uint32_t c0_in = fn_apply(fex, c0);
+    const uint32_t bytes = c0_in ? e.out_base : e.cur_start;
+    const uint32_t isum = wave_incl_sum(bytes);
+    if (t < nt) row[t] = RleCarry{exm ? exm - 1 : 0u, c0_in, out + isum - bytes, 0u};
+    const uint32_t last_m = (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+    prevb = last_m > prevb ? last_m : prevb;
+    c0 = fn_apply((uint32_t)__builtin_amdgcn_readlane((int)incl, 63), c0);
+    out += (uint32_t)__builtin_amdgcn_readlane((int)isum, 63);
+  }
+  if (lane == 0) blocks[blockIdx.x].out_len = out;
 }
 // write pass: every tile of every block by itself
 __global__ __launch_bounds__(1024) void unrle1_write(const uint8_t* __restrict__ wbuf, const IbBlock* __restrict__ blocks, const RleCarry* __restrict__ carry,
@@ -1264,7 +1427,8 @@ __global__ __launch_bounds__(1024) void unrle1_write(const uint8_t* __restrict__
   const uint32_t base = blockIdx.x * UR_TILE;
   if (base >= b.count) return;
   RleCarry cy = carry[(size_t)blockIdx.y * tiles_per_block + blockIdx.x];
-  unrle1_tile<true>(wbuf + b.woff, b.count, base, cy, out + b.out_off, sm, fnarr, posarr);
+  __shared__ __attribute__((aligned(16))) uint8_t stage[UR_STAGE + 16];
+  unrle1_tile<true>(wbuf + b.woff, b.count, base, cy, out + b.out_off, sm, fnarr, posarr, stage);
 }
 
 __global__ void ib_make_crc_ranges(const IbBlock* __restrict__ blocks, uint32_t nblocks, RleBlock* __restrict__ ranges, uint32_t* __restrict__ nb_dev) {
@@ -1620,7 +1784,12 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, q.d_blocks, nb, spl_stride, q.snext, q.ssteps, q.srank, q.d_err);
     hipLaunchKernelGGL(ib_walk2, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.srank, q.ssteps, d_wb, 0);
     hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, q.d_blocks, q.d_err, d_wb);
-    hipLaunchKernelGGL(unrle1_count, dim3(nb), dim3(1024), 0, s, d_wb, q.d_blocks, S->d_carry + (size_t)(b0 - S->c0) * S->carry_tiles, S->carry_tiles);
+    {
+      RleCarry* cr = S->d_carry + (size_t)(b0 - S->c0) * S->carry_tiles;
+      hipLaunchKernelGGL(unrle1_bounds, dim3(S->carry_tiles, nb), dim3(1024), 0, s, d_wb, q.d_blocks, cr, S->carry_tiles);
+      hipLaunchKernelGGL(unrle1_sums, dim3(S->carry_tiles, nb), dim3(1024), 0, s, d_wb, q.d_blocks, cr, S->carry_tiles);
+      hipLaunchKernelGGL(unrle1_carries, dim3(nb), dim3(64), 0, s, q.d_blocks, cr, S->carry_tiles);
+    }
     std::vector<int32_t> errs(nb);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(J->chain.data() + b0, q.d_blocks, sizeof(IbBlock) * nb, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(errs.data(), q.d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = CJS_E_HIP; break; }
