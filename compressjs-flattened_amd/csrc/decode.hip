@@ -1009,8 +1009,14 @@ __device__ __forceinline__ bool walk_item(uint32_t nblocks, uint32_t cpb, uint32
   return true;
 }
 constexpr uint32_t SPL_END = 0xFFFFFFFEu;   // the chain left the block (sentinel variant: the row of the implicit end marker)
+// `seg` (cyclic form): the walk also KEEPS what it reads -- the bytes of the first SEG_CAP slots it visits, SEG_CAP bytes per splitter,
+// sixteen at a time -- and the slot it stands on after SEG_CAP steps (`resume`): once the splitters are ranked the bytes only have
+// to be put in their places (ib_place), and a second walk (ib_walk2) is left for what the few long stretches hold behind SEG_CAP.
+// (Both walks were the same 100 M random 4-byte reads, a 64-byte line each: about 1.1 ms per 100 MB apiece.)
+constexpr uint32_t SEG_CAP = 384;           // a stretch is longer with probability e^-6
 __global__ __launch_bounds__(WALK_T) void ib_walk1(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t cpb,
-                                                   uint32_t spl_stride, uint32_t* __restrict__ spl_next, uint32_t* __restrict__ spl_steps, int sentinel) {
+                                                   uint32_t spl_stride, uint32_t* __restrict__ spl_next, uint32_t* __restrict__ spl_steps, int sentinel,
+                                                   uint8_t* __restrict__ seg, uint32_t* __restrict__ resume) {
   uint32_t blk, sidx;
   if (!walk_item(nblocks, cpb, blk, sidx)) return;
   const IbBlock b = blocks[blk];
@@ -1022,9 +1028,62 @@ __global__ __launch_bounds__(WALK_T) void ib_walk1(const uint32_t* __restrict__ 
   if (sidx == nspl - 1) { pos = start; if ((start % SPL) == 0) { spl_steps[(size_t)blk * spl_stride + sidx] = 0; spl_next[(size_t)blk * spl_stride + sidx] = start / SPL; return; } }
   else pos = sidx * SPL;
   uint32_t steps = 0, cur = pos;
-  do { cur = d[cur] >> 8; steps++; } while (cur < b.count && !is_split(cur, start) && steps < b.count);
+  if (seg) {
+    uint4* sb = reinterpret_cast<uint4*>(seg + ((size_t)blk * spl_stride + sidx) * SEG_CAP);
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    do {
+      const uint32_t e = d[cur];
+      if (steps < SEG_CAP) {
+        const uint32_t k = (steps >> 2) & 3u;
+#pragma unroll
+        for (int t = 0; t < 4; t++) if (k == (uint32_t)t) acc[t] = (acc[t] >> 8) | (e << 24);
+        if ((steps & 15u) == 15u) sb[steps >> 4] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+      }
+      cur = e >> 8; steps++;
+      if (steps == SEG_CAP) resume[(size_t)blk * spl_stride + sidx] = cur;
+    } while (cur < b.count && !is_split(cur, start) && steps < b.count);
+    if (steps < SEG_CAP && (steps & 15u)) {                    // the open piece: its words' bytes stand at the top
+      const uint32_t k = (steps >> 2) & 3u, r = 8u * (4u - (steps & 3u));
+#pragma unroll
+      for (int t = 0; t < 4; t++) if (k == (uint32_t)t && (steps & 3u)) acc[t] >>= r;
+      sb[steps >> 4] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+    }
+  } else {
+    do { cur = d[cur] >> 8; steps++; } while (cur < b.count && !is_split(cur, start) && steps < b.count);
+  }
   spl_steps[(size_t)blk * spl_stride + sidx] = steps;
   spl_next[(size_t)blk * spl_stride + sidx] = cur >= b.count ? SPL_END : (cur == start && (start % SPL) != 0) ? nspl - 1 : cur / SPL;
+}
+// the kept bytes of 64 stretches (splitters s0 .. s0 + 63 of block b, their ranks and lengths one per lane) to their places: four
+// stretches in flight at a time, the lanes along the bytes
+__device__ __forceinline__ void ib_place64(const IbBlock& b, size_t at0, uint32_t s0, uint32_t nspl, const uint32_t* __restrict__ spl_rank,
+                                           const uint32_t* __restrict__ spl_steps, const uint8_t* __restrict__ seg, uint8_t* __restrict__ w) {
+  const int lane = lane_id();
+  uint32_t rank = 0, nbytes = 0;
+  if (s0 + lane < nspl) {
+    rank = spl_rank[at0 + lane];
+    const uint32_t steps = spl_steps[at0 + lane];
+    if (rank != 0xFFFFFFFFu && steps != 0 && rank < b.count) nbytes = min(min(steps, SEG_CAP), b.count - rank);
+  }
+  const uint8_t* src = seg + at0 * SEG_CAP;
+  for (int i = 0; i < 64; i += 4) {
+    uint32_t r[4], nb[4], mx = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { r[j] = (uint32_t)__builtin_amdgcn_readlane((int)rank, i + j); nb[j] = (uint32_t)__builtin_amdgcn_readlane((int)nbytes, i + j); mx = max(mx, nb[j]); }
+    for (uint32_t o = lane; o < mx; o += 64) {
+      uint8_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = o < nb[j] ? src[(size_t)(i + j) * SEG_CAP + o] : (uint8_t)0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (o < nb[j]) w[r[j] + o] = v[j];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ib_place(const IbBlock* __restrict__ blocks, uint32_t spl_stride, const uint32_t* __restrict__ spl_rank,
+                                                const uint32_t* __restrict__ spl_steps, const uint8_t* __restrict__ seg, uint8_t* __restrict__ wbuf) {
+  const IbBlock b = blocks[blockIdx.y];
+  const uint32_t nspl = (b.count + SPL - 1) / SPL + 1, s0 = (blockIdx.x * 4u + (uint32_t)wave_id()) * 64u;
+  if (s0 < nspl) ib_place64(b, (size_t)blockIdx.y * spl_stride + s0, s0, nspl, spl_rank, spl_steps, seg, wbuf + b.woff);
 }
 // rank the splitter chain from `start`: spl_rank[s] = number of output positions before splitter s's segment.
 // One workgroup per block.  The chain is a list of <= 14064 nodes (a cycle through the start node for a cyclic BWT): the
@@ -1104,7 +1163,7 @@ __global__ __launch_bounds__(256) void ib_periodic_fill(const IbBlock* __restric
 // second walk: write the pre-RLE1 byte sequence w[0..n) of each block (w[r] = byte of the (r+1)-th visited slot)
 __global__ __launch_bounds__(WALK_T) void ib_walk2(const uint32_t* __restrict__ dbuf, const IbBlock* __restrict__ blocks, uint32_t nblocks, uint32_t cpb,
                                                    uint32_t spl_stride, const uint32_t* __restrict__ spl_rank, const uint32_t* __restrict__ spl_steps,
-                                                   uint8_t* __restrict__ wbuf, int sentinel) {
+                                                   uint8_t* __restrict__ wbuf, int sentinel, const uint32_t* __restrict__ resume, const uint8_t* __restrict__ seg) {
   uint32_t blk, sidx;
   if (!walk_item(nblocks, cpb, blk, sidx)) return;
   const IbBlock b = blocks[blk];
@@ -1113,9 +1172,14 @@ __global__ __launch_bounds__(WALK_T) void ib_walk2(const uint32_t* __restrict__ 
   const uint32_t nspl = (b.count + SPL - 1) / SPL + 1;
   if (sidx >= nspl) return;
   const uint32_t start = sentinel ? 0u : d[b.orig] >> 8;
-  const uint32_t rank = spl_rank[(size_t)blk * spl_stride + sidx], steps = spl_steps[(size_t)blk * spl_stride + sidx];
+  uint32_t rank = spl_rank[(size_t)blk * spl_stride + sidx], steps = spl_steps[(size_t)blk * spl_stride + sidx];
   if (rank == 0xFFFFFFFFu || steps == 0) return;
   uint32_t cur = sidx == nspl - 1 ? start : sidx * SPL;
+  if (seg) {                                      // only what ib_walk1 did not keep: from the slot it stood on after SEG_CAP steps
+    if (steps <= SEG_CAP) return;
+    cur = resume[(size_t)blk * spl_stride + sidx]; rank += SEG_CAP; steps -= SEG_CAP;
+    if (rank >= b.count) return;
+  }
   // visiting order: position `rank` of the walk is slot `cur`; the loop outputs the byte of every visited slot (:1735-1736)
   if (sentinel) {
     for (uint32_t q = 0; q < steps && rank + q < b.count; q++) {
@@ -1482,9 +1546,9 @@ static int ibwt_sentinel_slab(hipStream_t s, const uint8_t* d_T, uint32_t max_le
   uint32_t* d_dbuf = cur ? d_key0 : d_key1;
   hipLaunchKernelGGL(ib_pack_sentinel, dim3(64, nb), dim3(256), 0, s, d_blocks, sval, d_dbuf);
   const uint32_t cpb = walk_chunks(max_len), wgrid = ((nb * cpb + 7u) >> 3) << 3;
-  hipLaunchKernelGGL(ib_walk1, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, d_blocks, nb, cpb, spl_stride, d_snext, d_ssteps, 1);
+  hipLaunchKernelGGL(ib_walk1, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, d_blocks, nb, cpb, spl_stride, d_snext, d_ssteps, 1, nullptr, nullptr);
   hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, d_blocks, nb, spl_stride, d_snext, d_ssteps, d_srank, d_err);
-  hipLaunchKernelGGL(ib_walk2, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, d_blocks, nb, cpb, spl_stride, d_srank, d_ssteps, d_out, 1);
+  hipLaunchKernelGGL(ib_walk2, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, d_blocks, nb, cpb, spl_stride, d_srank, d_ssteps, d_out, 1, nullptr, nullptr);
   std::vector<int32_t> errs(nb);
   if (hipGetLastError() != hipSuccess || hipMemcpyAsync(errs.data(), d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
   cleanup();
@@ -1712,7 +1776,8 @@ void dec_phase_a(DecJob* J, DecShare* S) {
 // scratch of one inverse-BWT batch
 struct IbScratch {
   IbBlock* d_blocks = nullptr; uint32_t *key0 = nullptr, *key1 = nullptr, *val0 = nullptr, *val1 = nullptr;
-  uint32_t *snext = nullptr, *ssteps = nullptr, *srank = nullptr; int32_t* d_err = nullptr;
+  uint32_t *snext = nullptr, *ssteps = nullptr, *srank = nullptr, *resume = nullptr; int32_t* d_err = nullptr;
+  uint8_t* seg = nullptr;      // ib_walk1's kept bytes: SEG_CAP per splitter
   BwtWork sw;
 };
 
@@ -1737,7 +1802,6 @@ void dec_phase_b(DecJob* J, DecShare* S) {
   S->carry_tiles = (J->tt_stride + UR_TILE - 1) / UR_TILE;              // RLE1 state carried into every tile: written by phase B, read by phase C
   if (!rc) rc = S->take((void**)&S->d_carry, sizeof(RleCarry) * (size_t)nbk * S->carry_tiles);
   if (rc) { S->rc = rc; return; }
-  const uint32_t spl_stride = J->tt_stride / SPL + 4;
   for (size_t b0 = S->c0; b0 < S->c1 && !rc;) {
     const size_t b1 = dec_next_batch(J, b0, S->c1);
     const uint32_t nb = (uint32_t)(b1 - b0);
@@ -1748,6 +1812,7 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     uint32_t maxc = 0;
     for (size_t k = b0; k < b1; k++) maxc = std::max(maxc, J->chain[k].count);
     const uint32_t seg_stride = (maxc + 3u) & ~3u;
+    const uint32_t spl_stride = maxc / SPL + 4;                      // (of this batch: a file of very many small blocks must not pay for the largest level's)
     const bool strided = (uint64_t)nb * seg_stride <= M64 + M64 / 4 && (uint64_t)nb * seg_stride < 0xFFFFF000ull;
     const uint32_t M = strided ? nb * seg_stride : (uint32_t)M64;
     for (size_t k = b0; k < b1; k++) {
@@ -1760,6 +1825,11 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     if (!rc) rc = S->take((void**)&q.val0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.val1, 4 * (size_t)M + 64);
     if (!rc) rc = S->take((void**)&q.snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.ssteps, 4 * (size_t)nb * spl_stride);
     if (!rc) rc = S->take((void**)&q.srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.d_err, 4 * (size_t)nb);
+    if (!rc) rc = S->take((void**)&q.resume, 4 * (size_t)nb * spl_stride);
+    // (the first walk's kept bytes: without them -- one large block among very many tiny ones would ask for SEG_CAP x 14,066 bytes for
+    // each -- the second walk does all the work, as it does for the sentinel form)
+    const uint64_t seg_bytes = (uint64_t)nb * spl_stride * SEG_CAP;
+    if (!rc && seg_bytes <= (8ull << 30) && S->take((void**)&q.seg, (size_t)seg_bytes) != 0) q.seg = nullptr;
     const uint32_t tps = (seg_stride + RS_TILE - 1) / RS_TILE;
     const size_t T = strided ? (size_t)nb * tps + 1 : ((size_t)M + RS_TILE - 1) / RS_TILE + 1;
     if (!rc) rc = S->take((void**)&q.sw.hist, BwtWork::hist_words(T) * 4); if (!rc) rc = S->take((void**)&q.sw.bintot, 256 * 4 * (size_t)(strided ? nb : 1u));
@@ -1779,10 +1849,12 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     uint32_t* sval = cur ? q.val1 : q.val0;
     uint32_t* d_dbuf = cur ? q.key0 : q.key1;                      // the buffer the sort is not sitting in
     hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, q.d_blocks, sval, d_dbuf);
-    const uint32_t cpb = walk_chunks(J->tt_stride), wgrid = ((nb * cpb + 7u) >> 3) << 3;
-    hipLaunchKernelGGL(ib_walk1, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.snext, q.ssteps, 0);
+    const uint32_t cpb = walk_chunks(maxc), wgrid = ((nb * cpb + 7u) >> 3) << 3;
+    hipLaunchKernelGGL(ib_walk1, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.snext, q.ssteps, 0, q.seg, q.resume);
     hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, q.d_blocks, nb, spl_stride, q.snext, q.ssteps, q.srank, q.d_err);
-    hipLaunchKernelGGL(ib_walk2, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.srank, q.ssteps, d_wb, 0);
+    // (placing inside the second walk, whose workgroups are few per CU, was no faster than the two launches: 0.49 vs 0.21 + 0.26 ms)
+    if (q.seg) hipLaunchKernelGGL(ib_place, dim3((spl_stride + 255) / 256, nb), dim3(256), 0, s, q.d_blocks, spl_stride, q.srank, q.ssteps, q.seg, d_wb);
+    hipLaunchKernelGGL(ib_walk2, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.srank, q.ssteps, d_wb, 0, q.resume, q.seg);
     hipLaunchKernelGGL(ib_periodic_fill, dim3(32, nb), dim3(256), 0, s, q.d_blocks, q.d_err, d_wb);
     {
       RleCarry* cr = S->d_carry + (size_t)(b0 - S->c0) * S->carry_tiles;
@@ -1795,7 +1867,7 @@ void dec_phase_b(DecJob* J, DecShare* S) {
         hipMemcpyAsync(errs.data(), q.d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = CJS_E_HIP; break; }
     for (uint32_t k = 0; k < nb; k++) if (errs[k] <= 0) rc = CJS_E_DATA_ERROR;      // cannot happen: the walk makes >= 1 step
     S->drop(q.d_blocks); S->drop(q.key0); S->drop(q.key1); S->drop(q.val0); S->drop(q.val1); S->drop(q.snext); S->drop(q.ssteps);
-    S->drop(q.srank); S->drop(q.d_err); S->drop(q.sw.hist); S->drop(q.sw.bintot);
+    S->drop(q.srank); S->drop(q.d_err); S->drop(q.resume); if (q.seg) S->drop(q.seg); S->drop(q.sw.hist); S->drop(q.sw.bintot);
     b0 = b1;
   }
   if (S->d_tt) { S->drop(S->d_tt); S->d_tt = nullptr; }
