@@ -8,7 +8,7 @@ PKG       := compressjs-flattened_amd
 CSRC      := $(PKG)/csrc
 NODE_INC  ?= /usr/include/node
 
-HIPFLAGS  := -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+HIPFLAGS  := $(XFLAGS) -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 HIP_SRCS  := $(wildcard $(CSRC)/*.hip)
 HIP_HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 HIP_OBJS  := $(HIP_SRCS:.hip=.o)

@@ -721,7 +721,8 @@ __global__ __launch_bounds__(256) void bz_group_syms(const uint8_t* __restrict__
 //   weight 0, and with it the run is forgotten (the flush at :1643 tests the weight); a 33rd digit starts a fresh run.  So the
 //   digit of a run symbol is its position in the run mod 32, and a symbol with digit 31 takes back what the 31 in front of it added.
 //   rank symbols (>= 2) emit one byte each and leave as op (rank - 1, output offset); the bytes must fit the block (:1647, :1663).
-constexpr uint32_t SO_TILE = 4096;
+constexpr int SO_PT = 8;                       // symbols per thread (a tile is a dozen barriers whatever it holds: 0.58 / 0.47 / 0.87 ms per 100 MB with 4 / 8 / 16)
+constexpr uint32_t SO_TILE = 1024 * SO_PT, SO_KG = SO_TILE / GROUP_SYMS + 2;      // a tile's symbols lie in SO_KG groups at most
 __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, const Cand* __restrict__ cands, uint32_t ncand, const uint16_t* __restrict__ syms_all,
                                                    uint32_t sym_groups, uint32_t dbuf_size, uint8_t* __restrict__ ops_all, uint32_t* __restrict__ opoff_all,
                                                    uint32_t ops_stride, uint32_t* __restrict__ nops_all, BlockOut* __restrict__ outs, uint32_t row0, uint64_t nbits) {
@@ -746,24 +747,27 @@ __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, co
   if (tid < 32) st[tid] = 2;                     // in front of the first symbol: not a run
   for (uint32_t base = 0; base < nsym && !err; base += SO_TILE) {
     __syncthreads();
-    {                                             // the tile's symbols lie in 83 groups at most: along the groups, symbol by symbol of the group
+    {                                             // along the groups, symbol by symbol of the group
       const uint32_t k0 = base / GROUP_SYMS;
-      uint32_t at[5]; uint16_t v[5];
+      constexpr int LR = (GROUP_SYMS * SO_KG + 1023) / 1024;
+      for (int q0 = 0; q0 < LR; q0 += 6) {
+        uint32_t at[6]; uint16_t v[6];
 #pragma unroll
-      for (int q = 0; q < 5; q++) {                // (all five loads on their way before the first is stored)
-        const uint32_t u = (uint32_t)tid + 1024u * q, j = u / 83u, k = k0 + (u - 83u * j), i = k * GROUP_SYMS + j;
-        const bool in = u < GROUP_SYMS * 83u && i >= base && i < base + SO_TILE;
-        at[q] = in ? 32u + i - base : ~0u;
-        v[q] = in && i < nsym ? syms[(size_t)j * sym_groups + k] : (uint16_t)2;
+        for (int q = 0; q < 6; q++) {              // (six loads on their way before the first is stored)
+          const uint32_t u = (uint32_t)tid + 1024u * (uint32_t)(q0 + q), j = u / SO_KG, k = k0 + (u - SO_KG * j), i = k * GROUP_SYMS + j;
+          const bool in = q0 + q < LR && u < GROUP_SYMS * SO_KG && i >= base && i < base + SO_TILE;
+          at[q] = in ? 32u + i - base : ~0u;
+          v[q] = in && i < nsym ? syms[(size_t)j * sym_groups + k] : (uint16_t)2;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (at[q] != ~0u) st[at[q]] = v[q];
       }
-#pragma unroll
-      for (int q = 0; q < 5; q++) if (at[q] != ~0u) st[at[q]] = v[q];
     }
     __syncthreads();
     // position in the run: i - (index of the last rank symbol in front of i) - 1, by a max scan of (index + 1) of the rank symbols
     uint32_t lastb = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const uint32_t i = base + (uint32_t)tid * 4u + q; if (i < nsym && st[32 + tid * 4 + q] >= 2) lastb = i + 1; }
+    for (int q = 0; q < SO_PT; q++) { const uint32_t i = base + (uint32_t)tid * (uint32_t)SO_PT + q; if (i < nsym && st[32 + tid * SO_PT + q] >= 2) lastb = i + 1; }
     const uint32_t incl = block_incl_max<1024>(lastb, sm);
     mx[tid] = incl;
     __syncthreads();
@@ -771,17 +775,17 @@ __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, co
     const uint32_t tile_last = mx[1023];
     __syncthreads();
     if (prevnr < last_nonrun) prevnr = last_nonrun;
-    long long cb[4]; unsigned long long mine = 0; uint32_t nops = 0;
+    long long cb[SO_PT]; unsigned long long mine = 0; uint32_t nops = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t i = base + (uint32_t)tid * 4u + q, sy = st[32 + tid * 4 + q];
+    for (int q = 0; q < SO_PT; q++) {
+      const uint32_t i = base + (uint32_t)tid * (uint32_t)SO_PT + q, sy = st[32 + tid * SO_PT + q];
       cb[q] = 0;
       if (i < nsym) {
         if (sy >= 2) { cb[q] = 1; nops++; prevnr = i + 1; }
         else {
           const uint32_t d = (i - prevnr) & 31u;
           if (d < 31) cb[q] = (long long)(sy + 1u) << d;
-          else { long long t = 0; for (uint32_t b = 1; b <= 31; b++) t += (long long)((uint32_t)st[32 + tid * 4 + q - b] + 1u) << (31u - b); cb[q] = -t; }
+          else { long long t = 0; for (uint32_t b = 1; b <= 31; b++) t += (long long)((uint32_t)st[32 + tid * SO_PT + q - b] + 1u) << (31u - b); cb[q] = -t; }
         }
       }
       mine += (unsigned long long)cb[q];
@@ -791,8 +795,8 @@ __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, co
     uint32_t ntot;
     uint32_t jx = j0 + block_excl_sum<1024>(nops, sm, ntot);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t i = base + (uint32_t)tid * 4u + q, sy = st[32 + tid * 4 + q];
+    for (int q = 0; q < SO_PT; q++) {
+      const uint32_t i = base + (uint32_t)tid * (uint32_t)SO_PT + q, sy = st[32 + tid * SO_PT + q];
       if (i < nsym && sy >= 2) {
         if (jx < ops_stride - 1u && ex < 0xFFFFFFFFull) { ops[jx] = (uint8_t)(sy - 1u); opoff[jx] = (uint32_t)ex; }      // rank symbol s reads list slot s - 1 (:1664)
         jx++;
