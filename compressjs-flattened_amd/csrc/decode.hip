@@ -1907,32 +1907,13 @@ void dec_phase_c(DecJob* J, DecShare* S) {
     if (!rc) rc = S->take((void**)&d_crc, 4 * (size_t)nb);
     if (!rc && hipMemcpyAsync(d_blocks, blk.data(), sizeof(IbBlock) * nb, hipMemcpyHostToDevice, s) != hipSuccess) rc = CJS_E_HIP;
     if (rc) break;
-    // In pieces of blocks: the bytes of a piece go down (second stream) while the next piece is expanded and checked -- the copy
-    // is the longer of the two (100 MB: 1.8 ms against 0.55), so what is hidden is the kernels' time.
-    const uint32_t pieces = (J->host && obytes >= (32u << 20) && nb >= 4) ? 4u : 1u;
-    hipStream_t s2 = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (pieces > 1) {
-      if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) rc = CJS_E_HIP;
-      for (uint32_t p = 0; p < pieces && !rc; p++) if (hipEventCreateWithFlags(&ev[p], hipEventDisableTiming) != hipSuccess) rc = CJS_E_HIP;
-    }
+    hipLaunchKernelGGL(unrle1_write, dim3(S->carry_tiles, nb), dim3(1024), 0, s, S->d_w + e0, d_blocks, S->d_carry + (size_t)(b0 - S->c0) * S->carry_tiles, S->carry_tiles, d_out);
+    hipLaunchKernelGGL(ib_make_crc_ranges, dim3((nb + 63) / 64), dim3(64), 0, s, d_blocks, nb, d_ranges, d_nb);
+    rc = crc_ranges(s, d_out, d_ranges, d_nb, nb, need_segs, d_seg, d_crc);
     std::vector<uint32_t> crcs(nb);
-    for (uint32_t p = 0; p < pieces && !rc; p++) {
-      const uint32_t k0 = (uint32_t)((uint64_t)nb * p / pieces), k1 = (uint32_t)((uint64_t)nb * (p + 1) / pieces), nbp = k1 - k0;
-      const uint64_t po = blk[k0].out_off, pb = (k1 < nb ? blk[k1].out_off : obytes) - po;
-      hipLaunchKernelGGL(unrle1_write, dim3(S->carry_tiles, nbp), dim3(1024), 0, s, S->d_w + e0, d_blocks + k0, S->d_carry + (size_t)(b0 - S->c0 + k0) * S->carry_tiles, S->carry_tiles, d_out);
-      hipLaunchKernelGGL(ib_make_crc_ranges, dim3((nbp + 63) / 64), dim3(64), 0, s, d_blocks + k0, nbp, d_ranges + k0, d_nb + p);
-      rc = crc_ranges(s, d_out, d_ranges + k0, d_nb + p, nbp, need_segs, d_seg + (size_t)k0 * need_segs, d_crc + k0);
-      if (rc) break;
-      if (pieces > 1) {
-        if (hipEventRecord(ev[p], s) != hipSuccess || hipStreamWaitEvent(s2, ev[p], 0) != hipSuccess ||
-            (pb && hipMemcpyAsync(J->host + o0 + po, d_out + po, (size_t)pb, hipMemcpyDeviceToHost, s2) != hipSuccess)) rc = CJS_E_HIP;
-      }
-    }
     if (!rc && hipMemcpyAsync(crcs.data(), d_crc, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-    if (!rc && pieces == 1 && J->host && obytes && hipMemcpyAsync(J->host + o0, d_out, (size_t)obytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
-    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = CJS_E_HIP;                    // (both streams drained on every path: the buffers go back to the pool)
-    if (s2) { if (hipStreamSynchronize(s2) != hipSuccess && !rc) rc = CJS_E_HIP; (void)hipStreamDestroy(s2); }
-    for (uint32_t p = 0; p < 4; p++) if (ev[p]) (void)hipEventDestroy(ev[p]);
+    if (!rc && J->host && obytes && hipMemcpyAsync(J->host + o0, d_out, (size_t)obytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = CJS_E_HIP;
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = CJS_E_HIP;
     if (!rc) for (uint32_t k = 0; k < nb; k++) if (crcs[k] != blk[k].crc) {                    // Bad block CRC (:1756-1761)
       snprintf(S->detail, sizeof S->detail, "Bad block CRC (got %x expected %x)", crcs[k], blk[k].crc);
       if (getenv("CJS_DEBUG")) fprintf(stderr, "[cjs dec] block %zu: Bad block CRC (got %08x expected %08x) out_len %u\n", b0 + k, crcs[k], blk[k].crc, blk[k].out_len);
