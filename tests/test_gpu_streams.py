@@ -452,11 +452,13 @@ def test_decode_row_batches_match_the_single_batch(oracle):
             "bad = cat.copy(); bad[bad.size // 3] ^= 0x10; rc3, _ = h.bzip2_decompress(bad, 1); "
             "print(rc, support.sha256(out), support.sha256(np.concatenate(parts)), rc2, len(tab), rc3, h.last_error_detail().split(' (')[0])")
     res = []
-    for env in ({}, {"CJS_DEC_ROW_BYTES": str(14 * 900000)}):
+    # ... and with the inverse BWT in batches of <= 1,000,000 / 2,000,000 elements (CJS_DEC_BATCH_ELEMS): batches of one block, of
+    # blocks of one size (one segmented radix pass) and of mixed sizes (the block number sorted on too)
+    for env in ({}, {"CJS_DEC_ROW_BYTES": str(14 * 900000)}, {"CJS_DEC_BATCH_ELEMS": "1000000"}, {"CJS_DEC_BATCH_ELEMS": "2000000"}):
         o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), cwd=ROOT, timeout=300)
         assert o.returncode == 0, o.stderr[-1500:]
         res.append(o.stdout.split())
-    assert res[0] == res[1], res
+    assert all(r == res[0] for r in res[1:]), res
     assert res[0][0] == "0" and res[0][1] == res[0][2] and res[0][3] == "0" and res[0][5] in ("-5", "-2")
 
 
