@@ -345,11 +345,12 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
 // ---------------------------------------------------------------- 2b. block decode in stages
 // The Huffman chain of a block looks serial -- the table changes every 50 symbols, so there is no self-synchronisation to exploit
 // -- but the only thing one group of 50 symbols hands to the next is WHERE IT ENDS.  So:
-//   bz_chain        one workgroup per candidate: header, selector list and code tables (wave 0), then group by group the bit
-//                   position 50 codes further on.  For every bit position i of the group's span (<= 50 x the table's longest
-//                   code) thread i looks up the length of the code that WOULD start there: next[i] = i + len.  Five rounds of
-//                   pointer doubling in LDS (next^2, next^4 .. next^32) and three hops (32 + 16 + 2) give next^50(0).  About ten
-//                   LDS round trips per 50 symbols instead of 50 x (lookup + hop) by one lone wave.
+//   bz_chain        one workgroup per candidate: header, selector list and code tables (wave 0, in 2048-bit stretches), then up to
+//                   four groups per step: for every bit position i of a group's positions thread i looks up the length of the code
+//                   that WOULD start there: next[i] = i + len.  Five rounds of pointer doubling in LDS (next^2 .. next^32) give
+//                   next^50(0) = 2 + 16 + 32 for the first group; the groups behind it get tables of their own over positions
+//                   placed ahead, built in the same rounds (chain_tables).  About ten LDS round trips per 200 symbols instead of
+//                   50 x (lookup + hop) per group by one lone wave.
 //   bz_group_syms   one lane per group, all groups of all candidates at once: the 50 symbols from the group's start; the first
 //                   end-of-block symbol and the first undecodable code of the block by 64-bit atomic minima.
 //   bz_sym_ops      one workgroup per candidate over the symbols in front of the end-of-block: RUNA/RUNB digits -> byte counts,
@@ -363,7 +364,7 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
 // Same results as the reference loop (:1597-1670): every way it can fail there is DATA_ERROR, so a block is good iff its first
 // end-of-block symbol comes before its first undecodable code, the selectors do not run out first, and the bytes fit the block.
 struct RowTab {                    // per candidate row, in global memory between the stages
-  uint16_t fast[6][1024];
+  uint16_t fast[6][1024];          // (sym << 5) | len by the next 10 bits, 0 = not decodable within 10 bits
   uint32_t first[6][22];
   uint16_t cnt[6][22], start[6][22], bysym[6][260];
   uint8_t minlen[8], maxlen[8];
