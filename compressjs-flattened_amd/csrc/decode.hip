@@ -32,7 +32,7 @@ int select_device(const cjs_opts* opts);
 template <typename K>
 int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit);
 template <typename K>
-int radix_pass_segments_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t nseg, uint32_t stride, int lo_bit, int hi_bit);
+int radix_pass_segments_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t nseg, uint32_t stride, int lo_bit, int hi_bit, bool noval);
 int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, const uint32_t* d_nblocks, uint32_t count, uint32_t max_segs,
                uint32_t* d_seg_crc, uint32_t* d_crc_out);
 }
@@ -965,24 +965,29 @@ struct IbBlock {            // per valid block, in stream order
 };
 
 // keys (block << 8 | byte), vals = i
-// `stride` > 0: every block owns `stride` slots (one segment of a segmented sort each); the slots behind its bytes hold the largest
-// digit, which the stable sort leaves behind everything real.
+// `stride` > 0: every block owns `stride` slots (one segment of a segmented sort each), and a key is (i << 8) | byte -- the index rides
+// on the key, there is no value array (a block has < 2^24 bytes); the slots behind the block's bytes hold the largest digit, which the
+// stable sort leaves behind everything real.
 __global__ __launch_bounds__(256) void ib_make_keys(const IbBlock* __restrict__ blocks, uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t stride) {
   const IbBlock b = blocks[blockIdx.y];
   const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
+  if (stride) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) key[b.off + i] = i < b.count ? (i << 8) | tt[i] : 0xFFu;
+    return;
+  }
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < b.count; i += gridDim.x * 256) {
     key[b.off + i] = ((uint32_t)blockIdx.y << 8) | tt[i];
     val[b.off + i] = i;
   }
-  for (uint32_t i = b.count + blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) { key[b.off + i] = 0xFFu; val[b.off + i] = 0; }
 }
 // after the stable sort: slot j of the block holds (T[j] << 8) | tt[j] == the reference's dbuf (:1686-1690):
 // the pointer comes from the sorted order, the low byte is the j-th DECODED byte (not the sorted one)
-__global__ __launch_bounds__(256) void ib_pack(const IbBlock* __restrict__ blocks, const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf) {
+// (on_key: the sorted array holds (i << 8) | sorted byte, see ib_make_keys)
+__global__ __launch_bounds__(256) void ib_pack(const IbBlock* __restrict__ blocks, const uint32_t* __restrict__ val, uint32_t* __restrict__ dbuf, int on_key) {
   const IbBlock b = blocks[blockIdx.y];
   const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < b.count; j += gridDim.x * 256)
-    dbuf[b.off + j] = (val[b.off + j] << 8) | tt[j];
+    dbuf[b.off + j] = (on_key ? val[b.off + j] & 0xFFFFFF00u : val[b.off + j] << 8) | tt[j];
 }
 // sentinel variant (BWT.unbwtransform, J/BWTC_joined_.js:1147-1168): next(t) = LF[t] + C[T[t]] (+1 below pidx) = the stable
 // sorted position of element t; slot t holds (next(t) << 8) | T[t].  b.orig carries pidx.
@@ -1827,7 +1832,7 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     IbScratch q;
     rc = S->take((void**)&q.d_blocks, sizeof(IbBlock) * nb);
     if (!rc) rc = S->take((void**)&q.key0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.key1, 4 * (size_t)M + 64);
-    if (!rc) rc = S->take((void**)&q.val0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.val1, 4 * (size_t)M + 64);
+    if (!strided) { if (!rc) rc = S->take((void**)&q.val0, 4 * (size_t)M + 64); if (!rc) rc = S->take((void**)&q.val1, 4 * (size_t)M + 64); }
     if (!rc) rc = S->take((void**)&q.snext, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.ssteps, 4 * (size_t)nb * spl_stride);
     if (!rc) rc = S->take((void**)&q.srank, 4 * (size_t)nb * spl_stride); if (!rc) rc = S->take((void**)&q.d_err, 4 * (size_t)nb);
     if (!rc) rc = S->take((void**)&q.resume, 4 * (size_t)nb * spl_stride);
@@ -1845,15 +1850,15 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     uint8_t* d_wb = S->d_w + e0;
     hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, q.d_blocks, q.key0, q.val0, strided ? seg_stride : 0u);
     int cur = 0;
-    if (strided) rc = radix_pass_segments_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, nb, seg_stride, 0, 8);
+    if (strided) rc = radix_pass_segments_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, nb, seg_stride, 0, 8, true);
     else {
       int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
       rc = radix_passes_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, M, 0, kbits);
     }
     if (rc) break;
-    uint32_t* sval = cur ? q.val1 : q.val0;
+    const uint32_t* sval = strided ? (cur ? q.key1 : q.key0) : (cur ? q.val1 : q.val0);      // (strided: the sorted keys carry the indices)
     uint32_t* d_dbuf = cur ? q.key0 : q.key1;                      // the buffer the sort is not sitting in
-    hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, q.d_blocks, sval, d_dbuf);
+    hipLaunchKernelGGL(ib_pack, dim3(64, nb), dim3(256), 0, s, q.d_blocks, sval, d_dbuf, strided ? 1 : 0);
     const uint32_t cpb = walk_chunks(maxc), wgrid = ((nb * cpb + 7u) >> 3) << 3;
     hipLaunchKernelGGL(ib_walk1, dim3(wgrid), dim3(WALK_T), WALK_LDS, s, d_dbuf, q.d_blocks, nb, cpb, spl_stride, q.snext, q.ssteps, 0, q.seg, q.resume);
     hipLaunchKernelGGL(ib_rank, dim3(nb), dim3(1024), 0, s, q.d_blocks, nb, spl_stride, q.snext, q.ssteps, q.srank, q.d_err);
@@ -1871,7 +1876,7 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(J->chain.data() + b0, q.d_blocks, sizeof(IbBlock) * nb, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(errs.data(), q.d_err, 4 * (size_t)nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = CJS_E_HIP; break; }
     for (uint32_t k = 0; k < nb; k++) if (errs[k] <= 0) rc = CJS_E_DATA_ERROR;      // cannot happen: the walk makes >= 1 step
-    S->drop(q.d_blocks); S->drop(q.key0); S->drop(q.key1); S->drop(q.val0); S->drop(q.val1); S->drop(q.snext); S->drop(q.ssteps);
+    S->drop(q.d_blocks); S->drop(q.key0); S->drop(q.key1); if (q.val0) S->drop(q.val0); if (q.val1) S->drop(q.val1); S->drop(q.snext); S->drop(q.ssteps);
     S->drop(q.srank); S->drop(q.d_err); S->drop(q.resume); if (q.seg) S->drop(q.seg); S->drop(q.sw.hist); S->drop(q.sw.bintot);
     b0 = b1;
   }
