@@ -1351,11 +1351,11 @@ int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, u
 template int radix_passes_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, int, int);
 // ... the same over nseg runs of `stride` elements, each sorted by itself (decode.hip: one run per block)
 template <typename K>
-int radix_pass_segments_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t nseg, uint32_t stride, int lo_bit, int hi_bit, bool noval) {
+int radix_pass_segments_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t nseg, uint32_t stride, int lo_bit, int hi_bit, bool noval, bool first_hist_ready) {
   const SegGeom sg{nseg, stride, stride, (stride + RS_TILE - 1) / RS_TILE};
-  return radix_passes<K>(s, w, k0, v0, k1, v1, cur, nseg * stride, lo_bit, hi_bit, nullptr, &sg, nullptr, noval);
+  return radix_passes<K>(s, w, k0, v0, k1, v1, cur, nseg * stride, lo_bit, hi_bit, nullptr, &sg, nullptr, noval, first_hist_ready);
 }
-template int radix_pass_segments_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, uint32_t, int, int, bool);
+template int radix_pass_segments_public<uint32_t>(hipStream_t, BwtWork&, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int&, uint32_t, uint32_t, int, int, bool, bool);
 
 // Which tile sorter: the LDS radix version costs the same whatever the groups look like (18 ps per suffix), the counting /
 // bitonic version is cheaper once the groups are tiny (round 2 of the bench text, 7.7 suffixes per group: 1.51 vs 1.82 ms;

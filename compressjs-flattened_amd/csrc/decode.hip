@@ -32,7 +32,7 @@ int select_device(const cjs_opts* opts);
 template <typename K>
 int radix_passes_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t n, int lo_bit, int hi_bit);
 template <typename K>
-int radix_pass_segments_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t nseg, uint32_t stride, int lo_bit, int hi_bit, bool noval);
+int radix_pass_segments_public(hipStream_t s, BwtWork& w, K* k0, uint32_t* v0, K* k1, uint32_t* v1, int& cur, uint32_t nseg, uint32_t stride, int lo_bit, int hi_bit, bool noval, bool first_hist_ready);
 int crc_ranges(hipStream_t s, const uint8_t* d_data, const RleBlock* d_blocks, const uint32_t* d_nblocks, uint32_t count, uint32_t max_segs,
                uint32_t* d_seg_crc, uint32_t* d_crc_out);
 }
@@ -965,20 +965,47 @@ struct IbBlock {            // per valid block, in stream order
 };
 
 // keys (block << 8 | byte), vals = i
-// `stride` > 0: every block owns `stride` slots (one segment of a segmented sort each), and a key is (i << 8) | byte -- the index rides
-// on the key, there is no value array (a block has < 2^24 bytes); the slots behind the block's bytes hold the largest digit, which the
-// stable sort leaves behind everything real.
 __global__ __launch_bounds__(256) void ib_make_keys(const IbBlock* __restrict__ blocks, uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t stride) {
   const IbBlock b = blocks[blockIdx.y];
   const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
-  if (stride) {
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) key[b.off + i] = i < b.count ? (i << 8) | tt[i] : 0xFFu;
-    return;
-  }
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < b.count; i += gridDim.x * 256) {
     key[b.off + i] = ((uint32_t)blockIdx.y << 8) | tt[i];
     val[b.off + i] = i;
   }
+}
+// For the segmented pass every block owns `stride` slots (one segment each), and a key is (i << 8) | byte -- the index rides on the
+// key, there is no value array (a block has < 2^24 bytes); the slots behind the block's bytes hold the largest digit, which the stable
+// sort leaves behind everything real.  One workgroup per radix tile (RS_TILE slots of a block's range): the keys, and the tile's count of
+// every byte -- the row of the histogram the pass would otherwise read the keys again for (four copies per wave, interleaved: see
+// rs_hist_bytes)
+__global__ __launch_bounds__(256) void ib_make_keys_hist(const IbBlock* __restrict__ blocks, uint32_t* __restrict__ key, uint32_t stride, uint32_t tps,
+                                                         uint32_t* __restrict__ hist) {
+  constexpr int HC = 4;
+  __shared__ uint32_t h[4 * 256 * HC];
+  const IbBlock b = blocks[blockIdx.y];
+  const uint8_t* __restrict__ tt = reinterpret_cast<const uint8_t*>(b.tt);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4 * HC; i++) h[i * 256 + tid] = 0;
+  __syncthreads();
+  uint32_t* hw = h + (tid >> 6) * 256 * HC + (tid & (HC - 1));
+  const uint32_t t0 = blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (uint32_t e = tid; e < RS_TILE; e += 256) {
+    const uint32_t i = t0 + e;
+    if (i < stride) {
+      const uint32_t by = i < b.count ? tt[i] : 0xFFu;
+      key[b.off + i] = i < b.count ? (i << 8) | by : 0xFFu;
+      atomicAdd(&hw[by * HC], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t sum = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (int r = 0; r < HC; r++) sum += h[w * 256 * HC + tid * HC + r];
+  hist[((size_t)blockIdx.y * tps + blockIdx.x) * 256 + tid] = sum;
 }
 // after the stable sort: slot j of the block holds (T[j] << 8) | tt[j] == the reference's dbuf (:1686-1690):
 // the pointer comes from the sorted order, the low byte is the j-th DECODED byte (not the sorted one)
@@ -1848,9 +1875,10 @@ void dec_phase_b(DecJob* J, DecShare* S) {
     if (!rc && hipMemsetAsync(q.d_err, 0, 4 * (size_t)nb, s) != hipSuccess) rc = CJS_E_HIP;
     if (rc) break;
     uint8_t* d_wb = S->d_w + e0;
-    hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, q.d_blocks, q.key0, q.val0, strided ? seg_stride : 0u);
+    if (strided) hipLaunchKernelGGL(ib_make_keys_hist, dim3(tps, nb), dim3(256), 0, s, q.d_blocks, q.key0, seg_stride, tps, q.sw.hist);
+    else hipLaunchKernelGGL(ib_make_keys, dim3(64, nb), dim3(256), 0, s, q.d_blocks, q.key0, q.val0, 0u);
     int cur = 0;
-    if (strided) rc = radix_pass_segments_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, nb, seg_stride, 0, 8, true);
+    if (strided) rc = radix_pass_segments_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, nb, seg_stride, 0, 8, true, true);
     else {
       int kbits = 8; { uint32_t x = nb - 1; while (x) { kbits++; x >>= 1; } }
       rc = radix_passes_public<uint32_t>(s, q.sw, q.key0, q.val0, q.key1, q.val1, cur, M, 0, kbits);
