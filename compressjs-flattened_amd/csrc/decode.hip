@@ -751,18 +751,17 @@ __global__ __launch_bounds__(1024) void bz_sym_ops(RowTab* __restrict__ tabs, co
     {                                             // along the groups, symbol by symbol of the group
       const uint32_t k0 = base / GROUP_SYMS;
       constexpr int LR = (GROUP_SYMS * SO_KG + 1023) / 1024;
-      for (int q0 = 0; q0 < LR; q0 += 6) {
-        uint32_t at[6]; uint16_t v[6];
+      uint32_t at[LR]; uint16_t v[LR];            // (all of a thread's loads on their way before the first is stored; fetching the tile
+                                                  // behind during this one's work as well: 0.44 -> 0.70 ms)
 #pragma unroll
-        for (int q = 0; q < 6; q++) {              // (six loads on their way before the first is stored)
-          const uint32_t u = (uint32_t)tid + 1024u * (uint32_t)(q0 + q), j = u / SO_KG, k = k0 + (u - SO_KG * j), i = k * GROUP_SYMS + j;
-          const bool in = q0 + q < LR && u < GROUP_SYMS * SO_KG && i >= base && i < base + SO_TILE;
-          at[q] = in ? 32u + i - base : ~0u;
-          v[q] = in && i < nsym ? syms[(size_t)j * sym_groups + k] : (uint16_t)2;
-        }
-#pragma unroll
-        for (int q = 0; q < 6; q++) if (at[q] != ~0u) st[at[q]] = v[q];
+      for (int q = 0; q < LR; q++) {
+        const uint32_t u = (uint32_t)tid + 1024u * (uint32_t)q, j = u / SO_KG, k = k0 + (u - SO_KG * j), i = k * GROUP_SYMS + j;
+        const bool in = u < GROUP_SYMS * SO_KG && i >= base && i < base + SO_TILE;
+        at[q] = in ? 32u + i - base : ~0u;
+        v[q] = in && i < nsym ? syms[(size_t)j * sym_groups + k] : (uint16_t)2;
       }
+#pragma unroll
+      for (int q = 0; q < LR; q++) if (at[q] != ~0u) st[at[q]] = v[q];
     }
     __syncthreads();
     // position in the run: i - (index of the last rank symbol in front of i) - 1, by a max scan of (index + 1) of the rank symbols
