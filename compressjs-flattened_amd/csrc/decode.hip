@@ -341,7 +341,6 @@ __device__ int dec_prologue(DecShared& S, BitReader& r, uint32_t dbuf_size, uint
   return err;
 }
 
-#define DEC_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_clk[i] = wall_clock64(); } while (0)
 // ---------------------------------------------------------------- 2b. block decode in stages
 // The Huffman chain of a block looks serial -- the table changes every 50 symbols, so there is no self-synchronisation to exploit
 // -- but the only thing one group of 50 symbols hands to the next is WHERE IT ENDS.  So:
@@ -1250,7 +1249,7 @@ __device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) { 
   return fn_apply(then, fn_apply(first, 0)) | (fn_apply(then, fn_apply(first, 1)) << 1);
 }
 // One tile (UR_TILE = 1024 threads x UR_BPT bytes) of a block by one workgroup.  Carried from the tiles in front: start of the current stretch,
-// c0 of the current stretch, output bytes so far; WRITE: the bytes go out, else they are only counted.
+// c0 of the current stretch, output bytes so far (from the length pass below); the bytes go out.
 constexpr int UR_BPT_C = 16;
 // A thread's UR_BPT = 16 bytes w[p0 .. p0 + 16) and the byte in front of them (0 at the block's first byte), bytes behind the block's
 // end as 0.  The address has any alignment (the same for the whole workgroup): two aligned 16-byte loads and a funnel shift (a byte
